@@ -1,0 +1,207 @@
+/*
+ * michigan_hip.h -- C ABI of libmichigan_hip.so (gfx950 / MI355X only).
+ *
+ * This is the drop-in boundary of the MichiGAN generator / discriminator / VGG
+ * hot path.  The reference has NO native code and NO FFI: its operator layer is
+ * Python calling ATen.  Every entry point below therefore
+ * cites the reference *call site* whose ATen work it replaces; the Python
+ * classes in michigan_amd/networks mirror the reference classes and reach the
+ * GPU only through these symbols (ctypes).
+ *
+ * Conventions
+ *   - every tensor is a raw device pointer; activations are NHWC
+ *     ([N][H][W][C], C innermost); dtype is MG_F32 or MG_BF16 (accumulation is
+ *     always fp32; statistics are always fp32)
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream)
+ *   - return value: 0 on success, non-zero error code otherwise;
+ *     mg_last_error() returns a thread-local message for the last failure
+ *   - no entry point allocates, frees or synchronises
+ */
+#ifndef MICHIGAN_HIP_H
+#define MICHIGAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_ABI_VERSION 1
+
+enum { MG_F32 = 0, MG_BF16 = 1 };
+enum { MG_ACT_NONE = 0, MG_ACT_RELU = 1, MG_ACT_LRELU = 2, MG_ACT_TANH = 3 };
+enum { MG_EPI_PLAIN = 0, MG_EPI_SPADE = 1 };
+enum { MG_OK = 0, MG_ERR_ARG = 1, MG_ERR_LAUNCH = 2, MG_ERR_UNSUPPORTED = 3 };
+
+#define MG_MAX_TAPS 64
+
+/* ---------------------------------------------------------------------------
+ * mg_conv_taps -- "tap list" implicit-GEMM convolution on the matrix cores.
+ *
+ *   out[n, jy*osy+ooy, jx*osx+oox, co] = epilogue( sum_t sum_ci
+ *        W[t][co][ci] * in[n, jy*isy+tap_dy[t], jx*isx+tap_dx[t], ci] )
+ *   for (jy,jx) in [0,Hj)x[0,Wj); input taps outside [0,Hin)x[0,Win) read 0.
+ *
+ * One kernel covers
+ *   forward  nn.Conv2d (3x3 / 4x4 / 7x7 / 1x1, stride 1|2, zero pad):
+ *            normalization.py:94-99,111-113 (SPADE mlp convs),
+ *            architecture.py:31-35,70-71,79 (conv_0/conv_1/conv_s),
+ *            generator.py:72,227 (conv_img), discriminator.py:84-96,
+ *            architecture.py:163-178 (VGG19 slices), encoder.py:172-181,
+ *            MaskGAN_networks.py:162-168 (ConvBlock)
+ *   dgrad    of the same convs (autograd convolution_backward, data part):
+ *            stride 1 = same kernel with flipped/transposed weights,
+ *            stride 2 = one launch per output-parity class with its tap subset
+ *
+ * Weights are pre-packed [ntaps][CoutP][Cin] in `dtype`, CoutP = Cout_gemm
+ * rounded up to a multiple of 128 with zero rows (packing is host-side glue).
+ * Cin must be a multiple of 8 (host pads small channel counts with zeros).
+ *
+ * Epilogues
+ *   MG_EPI_PLAIN: v = acc + bias[co] (+ resid[n,oy,ox,co]) ; out = act(v)
+ *   MG_EPI_SPADE: GEMM rows come in blocks of 64 = [32 gamma rows | 32 beta rows]
+ *                 of the same 32 output channels (mlp_gamma/mlp_beta fused,
+ *                 normalization.py:112-116).  For output channel c:
+ *                   xhat = (x - mean[c]) * rstd[c];  g1 = 1 + gamma;
+ *                   out  = act(xhat * g1 + beta);  gamma_out (optional) = g1
+ *                 gamma/beta never reach HBM.  Cout = C (stored channels),
+ *                 Cout_gemm = 2 * roundup(C, 32).
+ * ------------------------------------------------------------------------- */
+typedef struct mg_conv_desc {
+    const void* in;        /* [N][Hin][Win][Cin]                              */
+    const void* wt;        /* [ntaps][CoutP][Cin] packed, dtype               */
+    void*       out;       /* [N][Hout][Wout][Cout]                           */
+    const float* bias;     /* [Cout_gemm] (GEMM row order) or NULL            */
+    const void* resid;     /* PLAIN: same shape/dtype as out, or NULL         */
+    const void* x;         /* SPADE: un-normalised activations, shape of out  */
+    const float* mean;     /* SPADE: [Cout]                                   */
+    const float* rstd;     /* SPADE: [Cout]                                   */
+    void*       gamma_out; /* SPADE: optional (1+gamma), shape/dtype of out   */
+    int32_t dtype;
+    int32_t N, Hin, Win, Cin;
+    int32_t Hout, Wout, Cout;
+    int32_t Cout_gemm, CoutP;
+    int32_t Hj, Wj;
+    int32_t isy, isx;
+    int32_t osy, osx, ooy, oox;
+    int32_t ntaps;
+    int32_t epilogue;
+    int32_t act;
+    float   slope;         /* LeakyReLU negative slope                        */
+    int8_t  tap_dy[MG_MAX_TAPS];
+    int8_t  tap_dx[MG_MAX_TAPS];
+} mg_conv_desc;
+
+int mg_conv_taps(const mg_conv_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * mg_conv_wgrad -- weight gradient of a forward conv (autograd
+ * convolution_backward, weight part), split-K over output pixels:
+ *   dw[t][co][ci] += sum_{n,jy,jx} dy[n,jy,jx,co] * x[n, jy*isy+tap_dy[t], jx*isx+tap_dx[t], ci]
+ * dw is fp32 and is ACCUMULATED INTO with hardware float atomics (caller
+ * zeroes it).  dy has Cg channels per pixel in GEMM row order (for the fused
+ * SPADE conv that is the [gamma|beta] block order).  Cg and Cin multiples of 8.
+ * ------------------------------------------------------------------------- */
+typedef struct mg_wgrad_desc {
+    const void* x;         /* [N][Hin][Win][Cin]                              */
+    const void* dy;        /* [N][Hj][Wj][Cg]                                 */
+    float*      dw;        /* [ntaps][Cg][Cin] fp32                           */
+    int32_t dtype;
+    int32_t N, Hin, Win, Cin;
+    int32_t Hj, Wj, Cg;
+    int32_t isy, isx;
+    int32_t ntaps;
+    int32_t splitk;        /* 0 = choose automatically                        */
+    int32_t flags;         /* bit0: bf16 operands via ds_read_b64_tr_b16      */
+    int8_t  tap_dy[MG_MAX_TAPS];
+    int8_t  tap_dx[MG_MAX_TAPS];
+} mg_wgrad_desc;
+
+int mg_conv_wgrad(const mg_wgrad_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Per-channel statistics (sync-BN / instance-norm reduce).
+ *   x is [G][P][C]; sums[g][0][c] = sum_p x, sums[g][1][c] = sum_p x*x  (fp32).
+ *   G = 1, P = N*H*W for batch norm (sync_batchnorm/batchnorm.py:63-68,128-145:
+ *   F.batch_norm on one device, sum/ssum reduce on several); G = N, P = H*W for
+ *   nn.InstanceNorm2d (normalization.py:47-48, encoder.py:173-181).
+ *   `partial` is caller workspace of mg_stats_workspace(G,P,C) bytes; the
+ *   reduction is two-stage and deterministic (no atomics).
+ * ------------------------------------------------------------------------- */
+int64_t mg_stats_workspace(int32_t G, int64_t P, int32_t C);
+int mg_channel_stats(const void* x, int32_t dtype, int32_t G, int64_t P, int32_t C,
+                     float* sums /* [G][2][C] */, void* partial, void* stream);
+
+/* y = act((x - mean[g][c]) * rstd[g][c])   (InstanceNorm2d + LeakyReLU,
+ * discriminator.py:88-93, encoder.py:188-197) */
+int mg_norm_act_fwd(const void* x, void* y, int32_t dtype, int32_t G, int64_t P, int32_t C,
+                    const float* mean, const float* rstd, int32_t act, float slope, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Backward of  h = act(xhat * g1 + beta),  xhat = (x - mean) * rstd
+ * (SPADE: g1 = 1 + gamma; plain norm+act: g1 == NULL means 1, no beta).
+ *
+ * mg_norm_bwd_reduce: dpre = dh * act'(h);  dxhat = dpre * g1
+ *     sums[g][0][c] = sum_p dxhat ; sums[g][1][c] = sum_p dxhat * xhat
+ *     if dgb != NULL (SPADE): writes d[gamma|beta] in GEMM row order
+ *     ([P][2*roundup(C,32)]): dgamma = dpre * xhat, dbeta = dpre.
+ * mg_norm_bwd_apply:  dx = rstd * (dxhat - s1[g][c] - xhat * s2[g][c])
+ *     with s1 = sum_dxhat / n, s2 = sum_dxhat_xhat / n supplied by the host
+ *     (after the cross-rank all-reduce for sync-BN).
+ * Replaces autograd of normalization.py:105-116 + F.batch_norm / InstanceNorm.
+ * ------------------------------------------------------------------------- */
+int mg_norm_bwd_reduce(const void* dh, const void* h, const void* x, const void* g1,
+                       int32_t dtype, int32_t G, int64_t P, int32_t C,
+                       const float* mean, const float* rstd, int32_t act, float slope,
+                       void* dgb, float* sums /* [G][2][C] */, void* partial, void* stream);
+int mg_norm_bwd_apply(const void* dh, const void* h, const void* x, const void* g1,
+                      int32_t dtype, int32_t G, int64_t P, int32_t C,
+                      const float* mean, const float* rstd, const float* s1, const float* s2,
+                      int32_t act, float slope, void* dx, void* stream);
+
+/* dpre = dy * act'(y) for the activations fused in conv epilogues
+ * (ReLU: architecture.py:163-178, MaskGAN_networks.py:145; LeakyReLU:
+ * discriminator.py:85; tanh: generator.py:228). */
+int mg_act_bwd(const void* dy, const void* y, void* dpre, int32_t dtype, int64_t numel,
+               int32_t act, float slope, void* stream);
+
+/* nearest 2x upsample (generator.py:74 nn.Upsample(scale_factor=2)) and its
+ * adjoint (sum of the 2x2 children). */
+int mg_upsample2x_fwd(const void* x, void* y, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int mg_upsample2x_bwd(const void* dy, void* dx, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* F.avg_pool2d(k=3, s=2, p=1, count_include_pad=False) (discriminator.py:46-49) */
+int mg_avgpool3s2_fwd(const void* x, void* y, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int mg_avgpool3s2_bwd(const void* dy, void* dx, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* nn.MaxPool2d(2, 2) of the VGG tower (architecture.py:163-178); backward
+ * routes dy to the first maximal element of each 2x2 window (ATen order). */
+int mg_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int mg_maxpool2_bwd(const void* dy, const void* x, void* dx, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* background blend  y = bg * (1 - hair[p]) + x * (1 - back[p])
+ * (generator.py:186,197,208,219); hair/back are fp32 [P] single-channel masks.
+ * bwd: dbg = dy * (1 - hair), dx = dy * (1 - back). */
+int mg_blend_fwd(const void* bg, const void* x, const float* hair, const float* back, void* y,
+                 int32_t dtype, int64_t P, int32_t C, void* stream);
+int mg_blend_bwd(const void* dy, const float* hair, const float* back, void* dbg, void* dx,
+                 int32_t dtype, int64_t P, int32_t C, void* stream);
+
+/* Fused Adam over one flat fp32 parameter buffer (torch.optim.Adam semantics,
+ * pix2pix_model.py:137-145: eps 1e-8, no weight decay, bias correction).
+ * step is the 1-based step count. */
+int mg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                 int64_t numel, float lr, float beta1, float beta2, float eps, int32_t step,
+                 float grad_scale, void* stream);
+
+/* Hardware probes used by the test-suite (MFMA / ds_read_tr fragment maps). */
+int mg_probe_mfma_layout(float* out /* [3][64][16] */, void* stream);
+int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* out /* [64][4] */, void* stream);
+
+int         mg_abi_version(void);
+const char* mg_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MICHIGAN_HIP_H */

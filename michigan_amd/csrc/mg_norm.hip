@@ -1,0 +1,259 @@
+// mg_norm.hip -- per-channel statistics and normalisation forward/backward
+// (sync-BN inside SPADE, InstanceNorm2d in the discriminator / appearance encoder).
+//
+// All kernels are HBM-bound streaming passes over NHWC activations: a thread
+// owns one quad (4 consecutive channels) so a pixel row of C channels is read
+// by C/4 consecutive lanes as 8 B (bf16) / 16 B (f32) vector loads; the
+// reduction over pixels is two-stage and deterministic:
+//   stage 1  grid (chunks, G): register accumulation over the block's pixel
+//            chunk, LDS tree across the thread rows -> partial[g][chunk][2][C]
+//   stage 2  fp64 sum over chunks in a fixed order -> sums[g][2][C]
+#include "mg_common.h"
+
+namespace {
+
+constexpr int NTHR = 256;
+
+struct StatGeom { int tpr; int rpb; int nchunks; int64_t chunk; };
+
+static inline StatGeom stat_geom(int64_t P, int C)
+{
+    StatGeom g;
+    const int c4 = C / 4;
+    g.tpr = c4 < NTHR ? c4 : NTHR;
+    g.rpb = NTHR / g.tpr;
+    int64_t want = (P + (int64_t)g.rpb * 16 - 1) / ((int64_t)g.rpb * 16);   // >= 16 rows per thread
+    if (want > 2048) want = 2048;
+    if (want < 1) want = 1;
+    g.chunk = (P + want - 1) / want;
+    g.nchunks = (int)((P + g.chunk - 1) / g.chunk);
+    return g;
+}
+
+// MODE 0: plain (sum x, sum x^2).  MODE 1: norm backward (sum dxhat, sum dxhat*xhat [+ dgb]).
+template <typename T, int MODE>
+__global__ __launch_bounds__(NTHR) void reduce_stage1(
+    const T* __restrict__ x, const T* __restrict__ dh, const T* __restrict__ h, const T* __restrict__ g1,
+    const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dgb,
+    float* __restrict__ partial, int64_t P, int C, int tpr, int rpb, int64_t chunk, int act, float slope)
+{
+    __shared__ float red[NTHR * 8];
+    const int tid = threadIdx.x;
+    const int g = blockIdx.y, ck = blockIdx.x, nchunks = gridDim.x;
+    const int c4 = C / 4;
+    const bool active = tid < tpr * rpb;
+    const int tq = tid % tpr, tr = tid / tpr;
+    const int Cr2 = 2 * ((C + 31) / 32) * 32;
+
+    const int64_t p0 = (int64_t)ck * chunk;
+    const int64_t p1 = (p0 + chunk < P) ? p0 + chunk : P;
+
+    for (int qd = tq; qd < c4; qd += tpr) {           // one trip unless C > 1024
+        const int c = qd * 4;
+        float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4_t mu, rs;
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mu[j] = mean[(size_t)g * C + c + j]; rs[j] = rstd[(size_t)g * C + c + j]; }
+        }
+        if (active) {
+            for (int64_t p = p0 + tr; p < p1; p += rpb) {
+                const size_t o = ((size_t)g * P + p) * C + c;
+                const f32x4_t xv = ET<T>::load4(x + o);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { s[j] += xv[j]; ss[j] += xv[j] * xv[j]; }
+                } else {
+                    const f32x4_t dv = ET<T>::load4(dh + o);
+                    const f32x4_t hv = ET<T>::load4(h + o);
+                    f32x4_t gv = {1.f, 1.f, 1.f, 1.f};
+                    if (g1) gv = ET<T>::load4(g1 + o);
+                    f32x4_t dgam, dbet;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float dpre = dv[j] * mg_act_grad_from_out(hv[j], act, slope);
+                        const float xh = (xv[j] - mu[j]) * rs[j];
+                        const float dxh = dpre * gv[j];
+                        s[j] += dxh; ss[j] += dxh * xh;
+                        dgam[j] = dpre * xh; dbet[j] = dpre;
+                    }
+                    if (dgb) {
+                        const size_t ob = ((size_t)g * P + p) * Cr2 + (size_t)(c >> 5) * 64 + (c & 31);
+                        ET<T>::store4(dgb + ob, dgam);
+                        ET<T>::store4(dgb + ob + 32, dbet);
+                    }
+                }
+            }
+        }
+        // cross-row reduce through LDS (rows tr = 0..rpb-1 share quad tq)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[tid * 8 + j] = s[j]; red[tid * 8 + 4 + j] = ss[j]; }
+        __syncthreads();
+        if (active && tr == 0) {
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = red[tid * 8 + j];
+            for (int r = 1; r < rpb; ++r) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] += red[(tid + r * tpr) * 8 + j];
+            }
+            float* dst = partial + ((size_t)g * nchunks + ck) * 2 * C;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dst[c + j] = a[j]; dst[C + c + j] = a[4 + j]; }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void reduce_stage2(const float* __restrict__ partial, float* __restrict__ sums, int nchunks, int C2)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (i >= C2) return;
+    double a = 0.0;
+    const float* p = partial + (size_t)g * nchunks * C2 + i;
+    for (int k = 0; k < nchunks; ++k) a += (double)p[(size_t)k * C2];
+    sums[(size_t)g * C2 + i] = (float)a;
+}
+
+template <typename T>
+__global__ void norm_act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t nquads, int64_t P, int C,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope)
+{
+    const int c4 = C / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * blockDim.x) {
+        const int qd = (int)(i % c4);
+        const int64_t pix = i / c4;
+        const int g = (int)(pix / P);
+        const int c = qd * 4;
+        const f32x4_t xv = ET<T>::load4(x + i * 4);
+        f32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = mg_act((xv[j] - mean[(size_t)g * C + c + j]) * rstd[(size_t)g * C + c + j], act, slope);
+        ET<T>::store4(y + i * 4, o);
+    }
+}
+
+template <typename T>
+__global__ void norm_bwd_apply_kernel(const T* __restrict__ dh, const T* __restrict__ h, const T* __restrict__ x,
+                                      const T* __restrict__ g1, T* __restrict__ dx, int64_t nquads, int64_t P, int C,
+                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                      const float* __restrict__ s1, const float* __restrict__ s2, int act, float slope)
+{
+    const int c4 = C / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * blockDim.x) {
+        const int qd = (int)(i % c4);
+        const int64_t pix = i / c4;
+        const int g = (int)(pix / P);
+        const size_t sc = (size_t)g * C + qd * 4;
+        const f32x4_t dv = ET<T>::load4(dh + i * 4);
+        const f32x4_t hv = ET<T>::load4(h + i * 4);
+        const f32x4_t xv = ET<T>::load4(x + i * 4);
+        f32x4_t gv = {1.f, 1.f, 1.f, 1.f};
+        if (g1) gv = ET<T>::load4(g1 + i * 4);
+        f32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float r = rstd[sc + j];
+            const float xh = (xv[j] - mean[sc + j]) * r;
+            const float dxh = dv[j] * mg_act_grad_from_out(hv[j], act, slope) * gv[j];
+            o[j] = r * (dxh - s1[sc + j] - xh * s2[sc + j]);
+        }
+        ET<T>::store4(dx + i * 4, o);
+    }
+}
+
+static inline int ew_grid(int64_t n) { int64_t b = (n + NTHR - 1) / NTHR; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+template <typename T, int MODE>
+int run_reduce(const void* x, const void* dh, const void* h, const void* g1, const float* mean, const float* rstd,
+               void* dgb, int G, int64_t P, int C, float* sums, void* partial, int act, float slope, hipStream_t st)
+{
+    const StatGeom sg = stat_geom(P, C);
+    dim3 grid(sg.nchunks, G);
+    hipLaunchKernelGGL((reduce_stage1<T, MODE>), grid, dim3(NTHR), 0, st,
+                       (const T*)x, (const T*)dh, (const T*)h, (const T*)g1, mean, rstd, (T*)dgb,
+                       (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, act, slope);
+    MG_CHECK_LAUNCH("reduce_stage1");
+    dim3 grid2((2 * C + 255) / 256, G);
+    hipLaunchKernelGGL(reduce_stage2, grid2, dim3(256), 0, st, (const float*)partial, sums, sg.nchunks, 2 * C);
+    MG_CHECK_LAUNCH("reduce_stage2");
+    return MG_OK;
+}
+
+}  // namespace
+
+#define MG_CHECK_NORM_GEOM(name) \
+    MG_CHECK_ARG(dtype == MG_F32 || dtype == MG_BF16, name ": bad dtype %d", dtype); \
+    MG_CHECK_ARG(G > 0 && P > 0 && C > 0 && (C % 4) == 0 && C <= 1024, name ": bad geometry G=%d P=%ld C=%d (C must be a multiple of 4, <= 1024)", G, (long)P, C)
+
+extern "C" int64_t mg_stats_workspace(int32_t G, int64_t P, int32_t C)
+{
+    if (G <= 0 || P <= 0 || C <= 0) return 0;
+    const StatGeom sg = stat_geom(P, C);
+    return (int64_t)G * sg.nchunks * 2 * C * (int64_t)sizeof(float);
+}
+
+extern "C" int mg_channel_stats(const void* x, int32_t dtype, int32_t G, int64_t P, int32_t C,
+                                float* sums, void* partial, void* stream)
+{
+    MG_CHECK_NORM_GEOM("mg_channel_stats");
+    MG_CHECK_ARG(x && sums && partial, "mg_channel_stats: null pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MG_BF16)
+        return run_reduce<uint16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, G, P, C, sums, partial, 0, 0.f, st);
+    return run_reduce<float, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, G, P, C, sums, partial, 0, 0.f, st);
+}
+
+extern "C" int mg_norm_act_fwd(const void* x, void* y, int32_t dtype, int32_t G, int64_t P, int32_t C,
+                               const float* mean, const float* rstd, int32_t act, float slope, void* stream)
+{
+    MG_CHECK_NORM_GEOM("mg_norm_act_fwd");
+    MG_CHECK_ARG(x && y && mean && rstd, "mg_norm_act_fwd: null pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t nq = (int64_t)G * P * (C / 4);
+    if (dtype == MG_BF16)
+        hipLaunchKernelGGL(norm_act_fwd_kernel<uint16_t>, dim3(ew_grid(nq)), dim3(NTHR), 0, st,
+                           (const uint16_t*)x, (uint16_t*)y, nq, P, C, mean, rstd, act, slope);
+    else
+        hipLaunchKernelGGL(norm_act_fwd_kernel<float>, dim3(ew_grid(nq)), dim3(NTHR), 0, st,
+                           (const float*)x, (float*)y, nq, P, C, mean, rstd, act, slope);
+    MG_CHECK_LAUNCH("mg_norm_act_fwd");
+    return MG_OK;
+}
+
+extern "C" int mg_norm_bwd_reduce(const void* dh, const void* h, const void* x, const void* g1,
+                                  int32_t dtype, int32_t G, int64_t P, int32_t C,
+                                  const float* mean, const float* rstd, int32_t act, float slope,
+                                  void* dgb, float* sums, void* partial, void* stream)
+{
+    MG_CHECK_NORM_GEOM("mg_norm_bwd_reduce");
+    MG_CHECK_ARG(dh && h && x && mean && rstd && sums && partial, "mg_norm_bwd_reduce: null pointer");
+    MG_CHECK_ARG(dgb == nullptr || G == 1, "mg_norm_bwd_reduce: dgb output requires G == 1");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MG_BF16)
+        return run_reduce<uint16_t, 1>(x, dh, h, g1, mean, rstd, dgb, G, P, C, sums, partial, act, slope, st);
+    return run_reduce<float, 1>(x, dh, h, g1, mean, rstd, dgb, G, P, C, sums, partial, act, slope, st);
+}
+
+extern "C" int mg_norm_bwd_apply(const void* dh, const void* h, const void* x, const void* g1,
+                                 int32_t dtype, int32_t G, int64_t P, int32_t C,
+                                 const float* mean, const float* rstd, const float* s1, const float* s2,
+                                 int32_t act, float slope, void* dx, void* stream)
+{
+    MG_CHECK_NORM_GEOM("mg_norm_bwd_apply");
+    MG_CHECK_ARG(dh && h && x && mean && rstd && s1 && s2 && dx, "mg_norm_bwd_apply: null pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t nq = (int64_t)G * P * (C / 4);
+    if (dtype == MG_BF16)
+        hipLaunchKernelGGL(norm_bwd_apply_kernel<uint16_t>, dim3(ew_grid(nq)), dim3(NTHR), 0, st,
+                           (const uint16_t*)dh, (const uint16_t*)h, (const uint16_t*)x, (const uint16_t*)g1, (uint16_t*)dx,
+                           nq, P, C, mean, rstd, s1, s2, act, slope);
+    else
+        hipLaunchKernelGGL(norm_bwd_apply_kernel<float>, dim3(ew_grid(nq)), dim3(NTHR), 0, st,
+                           (const float*)dh, (const float*)h, (const float*)x, (const float*)g1, (float*)dx,
+                           nq, P, C, mean, rstd, s1, s2, act, slope);
+    MG_CHECK_LAUNCH("mg_norm_bwd_apply");
+    return MG_OK;
+}

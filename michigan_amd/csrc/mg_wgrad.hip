@@ -1,0 +1,258 @@
+// mg_wgrad.hip -- convolution weight gradient, split-K over output pixels.
+//
+// GEMM view per (tap, split):  dW[tap][co][ci] += sum_q dY[q][co] * X[pix(q)+tap][ci]
+//   rows (MFMA "i") = co, cols (MFMA "n") = ci, K = output pixels q.
+// NHWC keeps CHANNELS contiguous, but here K runs over PIXELS, so the MFMA
+// fragments (8 consecutive K per lane for bf16) are a transpose of the natural
+// image.  Tiles are staged pixel-major in LDS ([KP pixels][128 channels], the
+// coalesced global image) and transposed on the way out:
+//   bf16: ds_read_b64_tr_b16 (gfx950 hardware transpose read; each 16-lane group
+//         turns a [4 pixels][16 channels] block into 4-pixels-per-lane fragments),
+//         with a ds_read_u16 gather as a selectable fallback (flags bit0 = 0);
+//   f32 : v_mfma_f32_32x32x2_f32 takes one K value per lane, so the pixel-major
+//         image is read directly (32 consecutive floats per half-wave).
+// Partial sums are accumulated into the fp32 dW with hardware float atomics.
+#include "mg_common.h"
+
+namespace {
+
+constexpr int NTHR = 256;
+
+struct WgK {
+    const void* x; const void* dy; float* dw;
+    int N, Hin, Win, Cin, Hj, Wj, Cg, isy, isx, ntaps;
+    int K;            // N*Hj*Wj
+    int kper;         // pixels per split (multiple of KP)
+    int tiles_m, tiles_n, splitk;
+    int tap[MG_MAX_TAPS];
+};
+
+template <typename T, bool TR>
+__global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgK d)
+{
+    constexpr bool BF = (sizeof(T) == 2);
+    constexpr int KP  = BF ? 32 : 16;                       // pixels per stage
+    constexpr int EPP = 16 / (int)sizeof(T);
+    constexpr int PPR = 128 * (int)sizeof(T) / 16;          // 16-byte pieces per pixel row (128 channels)
+    constexpr int RPP = NTHR / PPR;                         // rows per pass
+    constexpr int NPASS = KP / RPP;                         // = 2
+    constexpr int RS  = BF ? 320 : 528;                     // LDS row stride in bytes
+    constexpr int OPB = KP * RS;                            // one operand tile
+    constexpr int STAGE = 2 * OPB;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    int tile;
+    {
+        const int nblk = gridDim.x, b = blockIdx.x;
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int tm = tile % d.tiles_m;  tile /= d.tiles_m;
+    const int tn = tile % d.tiles_n;  tile /= d.tiles_n;
+    const int tap = tile % d.ntaps;
+    const int split = tile / d.ntaps;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int kbeg = split * d.kper;
+    const int kend = min(d.K, kbeg + d.kper);
+    if (kbeg >= kend) return;
+
+    const int tp = d.tap[tap];
+    const int tdy = (int)(short)(tp & 0xffff), tdx = tp >> 16;
+
+    const T* __restrict__ X  = reinterpret_cast<const T*>(d.x);
+    const T* __restrict__ DY = reinterpret_cast<const T*>(d.dy);
+    const int HWj = d.Hj * d.Wj;
+
+    const int piece = tid % PPR, prow = tid / PPR;
+    const int ca = m0 + piece * EPP;      // dy channel of this thread's piece
+    const int cb = n0 + piece * EPP;      // x channel of this thread's piece
+    const bool cav = ca < d.Cg, cbv = cb < d.Cin;
+
+    uint4 ra[NPASS], rb[NPASS];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int q = k0 + prow + i * RPP;
+            uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+            if (q < kend) {
+                if (cav) va = *reinterpret_cast<const uint4*>(DY + ((size_t)q * d.Cg + ca));
+                if (cbv) {
+                    const int n = q / HWj, r = q - n * HWj;
+                    const int jy = r / d.Wj, jx = r - jy * d.Wj;
+                    const int iy = jy * d.isy + tdy, ix = jx * d.isx + tdx;
+                    if ((unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win)
+                        vb = *reinterpret_cast<const uint4*>(X + ((size_t)((n * d.Hin + iy) * d.Win + ix) * d.Cin + cb));
+                }
+            }
+            ra[i] = va; rb[i] = vb;
+        }
+    };
+    auto lstore = [&](int s) {
+        unsigned char* base = smem + s * STAGE;
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int row = prow + i * RPP;
+            *reinterpret_cast<uint4*>(base + row * RS + piece * 16) = ra[i];
+            *reinterpret_cast<uint4*>(base + OPB + row * RS + piece * 16) = rb[i];
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    auto compute = [&](int s) {
+        const unsigned char* As = smem + s * STAGE;
+        const unsigned char* Bs = As + OPB;
+        if constexpr (BF) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t a[2], b[2];
+                if constexpr (TR) {
+                    // 16-lane group g2: channel block (g2&1)*16, K half g2>>1 (= hi).
+                    const int i16 = lane & 15, g2 = lane >> 4;
+                    const int row = ks * 16 + (g2 >> 1) * 8 + (i16 >> 2);
+                    const int col = (g2 & 1) * 16 + (i16 & 3) * 4;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        typedef __attribute__((address_space(3))) s16x4_t* lp_t;
+                        const unsigned char* pa = As + row * RS + (wm * 64 + t * 32 + col) * 2;
+                        const unsigned char* pb = Bs + row * RS + (wn * 64 + t * 32 + col) * 2;
+                        s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(pa));
+                        s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(pa + 4 * RS));
+                        s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(pb));
+                        s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(pb + 4 * RS));
+                        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+                        s16x8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        s16x8_t bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        a[t] = __builtin_bit_cast(bf16x8_t, av);
+                        b[t] = __builtin_bit_cast(bf16x8_t, bv);
+                    }
+                } else {
+                    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        s16x8_t av, bv;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int row = ks * 16 + hi * 8 + j;
+                            av[j] = *reinterpret_cast<const short*>(As + row * RS + (wm * 64 + t * 32 + l31) * 2);
+                            bv[j] = *reinterpret_cast<const short*>(Bs + row * RS + (wn * 64 + t * 32 + l31) * 2);
+                        }
+                        a[t] = __builtin_bit_cast(bf16x8_t, av);
+                        b[t] = __builtin_bit_cast(bf16x8_t, bv);
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KP / 2; ++kk) {
+                float a[2], b[2];
+                const int row = kk * 2 + hi;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    a[t] = *reinterpret_cast<const float*>(As + row * RS + (wm * 64 + t * 32 + l31) * 4);
+                    b[t] = *reinterpret_cast<const float*>(Bs + row * RS + (wn * 64 + t * 32 + l31) * 4);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nk = (kend - kbeg + KP - 1) / KP;
+    gload(kbeg);
+    lstore(0);
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+        const bool more = (it + 1 < nk);
+        if (more) gload(kbeg + (it + 1) * KP);
+        compute(it & 1);
+        if (more) lstore((it + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- accumulate the tile into dW (fp32 atomics; lanes 0..31 = 32 consecutive ci)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int ci = n0 + wn * 64 + nt * 32 + l31;
+            if (ci >= d.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (co < d.Cg)
+                    atomicAdd(d.dw + ((size_t)(tap * d.Cg + co) * d.Cin + ci), acc[mt][nt][r]);
+            }
+        }
+}
+
+template <typename T, bool TR>
+int launch_wgrad(WgK& k, hipStream_t st)
+{
+    constexpr bool BF = (sizeof(T) == 2);
+    constexpr int KP = BF ? 32 : 16;
+    constexpr int RS = BF ? 320 : 528;
+    k.tiles_m = (k.Cg + 127) / 128;
+    k.tiles_n = (k.Cin + 127) / 128;
+    const long base = (long)k.tiles_m * k.tiles_n * k.ntaps;
+    int S = k.splitk;
+    if (S <= 0) {
+        S = (int)((1536 + base - 1) / base);                 // ~6 workgroups per CU in flight
+        const int maxS = (k.K + KP * 8 - 1) / (KP * 8);        // keep >= 8 stages per split
+        if (S > maxS) S = maxS;
+        if (S < 1) S = 1;
+    }
+    k.kper = ((k.K + S - 1) / S + KP - 1) / KP * KP;
+    S = (k.K + k.kper - 1) / k.kper;
+    k.splitk = S;
+    const long nblk = base * S;
+    if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_wgrad: bad grid %ld", nblk);
+    const size_t lds = 2 * 2 * (size_t)KP * RS;
+    hipLaunchKernelGGL((wgrad_kernel<T, TR>), dim3((unsigned)nblk), dim3(NTHR), lds, st, k);
+    MG_CHECK_LAUNCH("mg_conv_wgrad");
+    return MG_OK;
+}
+
+}  // namespace
+
+extern "C" int mg_conv_wgrad(const mg_wgrad_desc* d, void* stream)
+{
+    MG_CHECK_ARG(d != nullptr, "mg_conv_wgrad: null descriptor");
+    MG_CHECK_ARG(d->x && d->dy && d->dw, "mg_conv_wgrad: null tensor pointer");
+    MG_CHECK_ARG(d->dtype == MG_F32 || d->dtype == MG_BF16, "mg_conv_wgrad: bad dtype %d", d->dtype);
+    MG_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= MG_MAX_TAPS, "mg_conv_wgrad: ntaps=%d out of range", d->ntaps);
+    MG_CHECK_ARG(d->Cin > 0 && (d->Cin % 8) == 0 && d->Cg > 0 && (d->Cg % 8) == 0,
+                 "mg_conv_wgrad: Cin=%d / Cg=%d must be positive multiples of 8", d->Cin, d->Cg);
+    MG_CHECK_ARG(d->N > 0 && d->Hj > 0 && d->Wj > 0 && d->Hin > 0 && d->Win > 0, "mg_conv_wgrad: empty geometry");
+    MG_CHECK_ARG((long)d->N * d->Hj * d->Wj < (1L << 30), "mg_conv_wgrad: too many pixels");
+    WgK k;
+    k.x = d->x; k.dy = d->dy; k.dw = d->dw;
+    k.N = d->N; k.Hin = d->Hin; k.Win = d->Win; k.Cin = d->Cin;
+    k.Hj = d->Hj; k.Wj = d->Wj; k.Cg = d->Cg; k.isy = d->isy; k.isx = d->isx; k.ntaps = d->ntaps;
+    k.K = d->N * d->Hj * d->Wj; k.splitk = d->splitk; k.kper = 0; k.tiles_m = k.tiles_n = 0;
+    for (int t = 0; t < MG_MAX_TAPS; ++t)
+        k.tap[t] = t < d->ntaps ? (int)((((uint32_t)(int)d->tap_dy[t]) & 0xffffu) | (((uint32_t)(int)d->tap_dx[t]) << 16)) : 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == MG_BF16)
+        return (d->flags & 1) ? launch_wgrad<uint16_t, true>(k, st) : launch_wgrad<uint16_t, false>(k, st);
+    return launch_wgrad<float, false>(k, st);
+}
