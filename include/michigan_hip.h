@@ -198,6 +198,9 @@ int mg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
 int mg_probe_mfma_layout(float* out /* [3][64][16] */, void* stream);
 int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* out /* [64][4] */, void* stream);
 
+/* sizeof(mg_conv_desc) (which=0) / sizeof(mg_wgrad_desc) (which=1): lets a
+ * foreign-language binding check its struct mirror without a GPU. */
+int         mg_sizeof_desc(int32_t which);
 int         mg_abi_version(void);
 const char* mg_last_error(void);
 

@@ -1,0 +1,135 @@
+"""ctypes binding of libmichigan_hip.so -- the ONLY route from Python to the GPU kernels.
+
+Mirrors include/michigan_hip.h one to one (struct layouts are checked against
+``mg_sizeof_desc`` at load time).  There is deliberately no CPU or eager-PyTorch
+fallback here: if the shared library is missing or a call fails, the caller gets
+a RuntimeError.  The test-suite may swap the backend object (``set_backend``) for
+the contract emulator that lives under ``oracle/`` -- product code never does.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+MG_F32, MG_BF16 = 0, 1
+MG_ACT_NONE, MG_ACT_RELU, MG_ACT_LRELU, MG_ACT_TANH = 0, 1, 2, 3
+MG_EPI_PLAIN, MG_EPI_SPADE = 0, 1
+MG_MAX_TAPS = 64
+MG_ABI_VERSION = 1
+
+_i32, _f32, _vp, _i64 = ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
+
+
+class ConvDesc(ctypes.Structure):
+    """struct mg_conv_desc (include/michigan_hip.h)."""
+    _fields_ = [
+        ("in_", _vp), ("wt", _vp), ("out", _vp), ("bias", _vp), ("resid", _vp), ("x", _vp),
+        ("mean", _vp), ("rstd", _vp), ("gamma_out", _vp),
+        ("dtype", _i32), ("N", _i32), ("Hin", _i32), ("Win", _i32), ("Cin", _i32),
+        ("Hout", _i32), ("Wout", _i32), ("Cout", _i32), ("Cout_gemm", _i32), ("CoutP", _i32),
+        ("Hj", _i32), ("Wj", _i32), ("isy", _i32), ("isx", _i32),
+        ("osy", _i32), ("osx", _i32), ("ooy", _i32), ("oox", _i32),
+        ("ntaps", _i32), ("epilogue", _i32), ("act", _i32), ("slope", _f32),
+        ("tap_dy", ctypes.c_int8 * MG_MAX_TAPS), ("tap_dx", ctypes.c_int8 * MG_MAX_TAPS),
+    ]
+
+
+class WgradDesc(ctypes.Structure):
+    """struct mg_wgrad_desc (include/michigan_hip.h)."""
+    _fields_ = [
+        ("x", _vp), ("dy", _vp), ("dw", _vp),
+        ("dtype", _i32), ("N", _i32), ("Hin", _i32), ("Win", _i32), ("Cin", _i32),
+        ("Hj", _i32), ("Wj", _i32), ("Cg", _i32), ("isy", _i32), ("isx", _i32),
+        ("ntaps", _i32), ("splitk", _i32), ("flags", _i32),
+        ("tap_dy", ctypes.c_int8 * MG_MAX_TAPS), ("tap_dx", ctypes.c_int8 * MG_MAX_TAPS),
+    ]
+
+
+# name -> (argtypes, restype); descriptors are passed by reference.
+_PROTOS = {
+    "mg_conv_taps": ([ctypes.POINTER(ConvDesc), _vp], _i32),
+    "mg_conv_wgrad": ([ctypes.POINTER(WgradDesc), _vp], _i32),
+    "mg_stats_workspace": ([_i32, _i64, _i32], _i64),
+    "mg_channel_stats": ([_vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp], _i32),
+    "mg_norm_act_fwd": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _f32, _vp], _i32),
+    "mg_norm_bwd_reduce": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp], _i32),
+    "mg_norm_bwd_apply": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp], _i32),
+    "mg_act_bwd": ([_vp, _vp, _vp, _i32, _i64, _i32, _f32, _vp], _i32),
+    "mg_upsample2x_fwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "mg_upsample2x_bwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "mg_avgpool3s2_fwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "mg_avgpool3s2_bwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "mg_maxpool2_fwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "mg_maxpool2_bwd": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "mg_blend_fwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp], _i32),
+    "mg_blend_bwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp], _i32),
+    "mg_adam_step": ([_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp], _i32),
+    "mg_probe_mfma_layout": ([_vp, _vp], _i32),
+    "mg_probe_tr16": ([_vp, _vp, _vp], _i32),
+    "mg_sizeof_desc": ([_i32], _i32),
+    "mg_abi_version": ([], _i32),
+    "mg_last_error": ([], ctypes.c_char_p),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+_NO_STATUS = {"mg_stats_workspace", "mg_sizeof_desc", "mg_abi_version", "mg_last_error"}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmichigan_hip.so")
+
+
+class HipBackend:
+    """The real thing: every method is one C-ABI entry point of libmichigan_hip.so."""
+    name = "hip"
+
+    def __init__(self, path: str = LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"libmichigan_hip.so not found at {path}: build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                "michigan_amd has no CPU / eager-PyTorch fallback.")
+        # torch must already have loaded its libamdhip64 so that we bind to the same runtime.
+        import torch  # noqa: F401
+        self._lib = ctypes.CDLL(path)
+        for fn, (argtypes, restype) in _PROTOS.items():
+            f = getattr(self._lib, fn)          # AttributeError if a symbol is missing
+            f.argtypes, f.restype = argtypes, restype
+        if self._lib.mg_abi_version() != MG_ABI_VERSION:
+            raise RuntimeError("libmichigan_hip.so ABI version mismatch")
+        if self._lib.mg_sizeof_desc(0) != ctypes.sizeof(ConvDesc) or self._lib.mg_sizeof_desc(1) != ctypes.sizeof(WgradDesc):
+            raise RuntimeError("ctypes mirror of mg_conv_desc / mg_wgrad_desc is out of sync with the header")
+
+    def __getattr__(self, fn):
+        if fn not in _PROTOS:
+            raise AttributeError(fn)
+        raw = getattr(self._lib, fn)
+        if fn in _NO_STATUS:
+            return raw
+        by_ref = fn in ("mg_conv_taps", "mg_conv_wgrad")
+
+        def call(*args):
+            if by_ref:
+                args = (ctypes.byref(args[0]),) + tuple(args[1:])
+            rc = raw(*args)
+            if rc != 0:
+                msg = self._lib.mg_last_error()
+                raise RuntimeError(f"{fn} failed (code {rc}): {msg.decode() if msg else '?'}")
+            return rc
+        self.__dict__[fn] = call
+        return call
+
+
+_backend = None
+
+
+def backend():
+    """Return the active backend, loading libmichigan_hip.so on first use."""
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+def set_backend(obj):
+    """TEST HOOK ONLY (oracle/cabi_emulator.py): install a contract emulator, return the previous backend."""
+    global _backend
+    prev, _backend = _backend, obj
+    return prev

@@ -48,15 +48,17 @@ __global__ __launch_bounds__(NTHR) void reduce_stage1(
     const int64_t p0 = (int64_t)ck * chunk;
     const int64_t p1 = (p0 + chunk < P) ? p0 + chunk : P;
 
-    for (int qd = tq; qd < c4; qd += tpr) {           // one trip unless C > 1024
-        const int c = qd * 4;
+    for (int qd0 = 0; qd0 < c4; qd0 += tpr) {         // uniform trip count (one trip unless C > 1024)
+        const int qd = qd0 + tq;
+        const bool qv = active && qd < c4;
+        const int c = (qd < c4 ? qd : 0) * 4;
         float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
         f32x4_t mu, rs;
         if (MODE == 1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { mu[j] = mean[(size_t)g * C + c + j]; rs[j] = rstd[(size_t)g * C + c + j]; }
         }
-        if (active) {
+        if (qv) {
             for (int64_t p = p0 + tr; p < p1; p += rpb) {
                 const size_t o = ((size_t)g * P + p) * C + c;
                 const f32x4_t xv = ET<T>::load4(x + o);
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(NTHR) void reduce_stage1(
 #pragma unroll
         for (int j = 0; j < 4; ++j) { red[tid * 8 + j] = s[j]; red[tid * 8 + 4 + j] = ss[j]; }
         __syncthreads();
-        if (active && tr == 0) {
+        if (qv && tr == 0) {
             float a[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] = red[tid * 8 + j];
@@ -186,7 +188,7 @@ int run_reduce(const void* x, const void* dh, const void* h, const void* g1, con
 
 #define MG_CHECK_NORM_GEOM(name) \
     MG_CHECK_ARG(dtype == MG_F32 || dtype == MG_BF16, name ": bad dtype %d", dtype); \
-    MG_CHECK_ARG(G > 0 && P > 0 && C > 0 && (C % 4) == 0 && C <= 1024, name ": bad geometry G=%d P=%ld C=%d (C must be a multiple of 4, <= 1024)", G, (long)P, C)
+    MG_CHECK_ARG(G > 0 && P > 0 && C > 0 && (C % 4) == 0 && C <= 4096, name ": bad geometry G=%d P=%ld C=%d (C must be a multiple of 4, <= 4096)", G, (long)P, C)
 
 extern "C" int64_t mg_stats_workspace(int32_t G, int64_t P, int32_t C)
 {

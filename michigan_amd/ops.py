@@ -1,0 +1,574 @@
+"""Operator layer: torch.autograd.Functions whose forward AND backward are
+hand-written HIP kernels reached through the C ABI (michigan_amd._cabi).
+
+Tensor convention inside this module: activations are contiguous NHWC tensors
+``[N, H, W, C]`` in the compute dtype (``torch.bfloat16`` or ``torch.float32``);
+parameters stay fp32 in the reference's layouts and are re-packed per call into
+the GEMM-order image the kernels want (``[taps][Cout][Cin]``) with ordinary
+differentiable torch ops, so autograd carries weight gradients back through the
+packing (and through spectral-norm's division) without any hand-written
+un-packing.
+
+Reference call sites replaced (all ATen today):
+  conv2d            nn.Conv2d            normalization.py:94-99, architecture.py:31-35,
+                                         discriminator.py:84-96, architecture.py:163-178
+  spade_modulate    SPADE.forward        normalization.py:101-118
+  batch_stats       F.batch_norm / sync  sync_batchnorm/batchnorm.py:63-68,128-145
+  instance_norm_act InstanceNorm2d+lrelu normalization.py:47-48, discriminator.py:88-93
+  upsample2x / avgpool3s2 / maxpool2 / blend   generator.py:74,186 discriminator.py:46-49
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import _cabi as C
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = C.MG_ACT_NONE, C.MG_ACT_RELU, C.MG_ACT_LRELU, C.MG_ACT_TANH
+
+# Use the gfx950 LDS transpose-read path for bf16 weight gradients (flags bit0 of mg_wgrad_desc).
+WGRAD_USE_TR = True
+# Process group used to synchronise batch-norm statistics (set by michigan_amd.parallel); None = local stats.
+SYNC_BN_GROUP = None
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return C.MG_BF16
+    if t.dtype == torch.float32:
+        return C.MG_F32
+    raise TypeError(f"michigan_amd kernels compute in bfloat16 or float32, got {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    if t.is_cuda:
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return None
+
+
+def _roundup(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def _nhwc(t: torch.Tensor) -> torch.Tensor:
+    if t.dim() != 4:
+        raise ValueError(f"expected an NHWC 4-d tensor, got shape {tuple(t.shape)}")
+    return t.contiguous()
+
+
+def _set_taps(desc, taps: Sequence[Tuple[int, int]]):
+    if not 1 <= len(taps) <= C.MG_MAX_TAPS:
+        raise ValueError(f"{len(taps)} taps (max {C.MG_MAX_TAPS})")
+    desc.ntaps = len(taps)
+    for i, (dy, dx) in enumerate(taps):
+        desc.tap_dy[i] = dy
+        desc.tap_dx[i] = dx
+
+
+def fwd_taps(kh: int, kw: int, pad: int) -> List[Tuple[int, int]]:
+    return [(ky - pad, kx - pad) for ky in range(kh) for kx in range(kw)]
+
+
+def gemm_weight(weight: torch.Tensor, cin_pad: int) -> torch.Tensor:
+    """[Cout, Cin, kh, kw] -> GEMM order [kh*kw, Cout, cin_pad] (fp32, differentiable)."""
+    cout, cin, kh, kw = weight.shape
+    w = weight.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
+    if cin_pad > cin:
+        w = F.pad(w, (0, cin_pad - cin))
+    return w
+
+
+def pad_channels(x: torch.Tensor, mult: int = 8) -> torch.Tensor:
+    """Zero-pad the channel (last) dim of an NHWC tensor to a multiple of `mult` (differentiable)."""
+    c = x.shape[-1]
+    cp = _roundup(c, mult)
+    return x if cp == c else F.pad(x, (0, cp - c))
+
+
+# ----------------------------------------------------------------------------
+# raw launches
+# ----------------------------------------------------------------------------
+def _launch_conv(inp, wt, out, bias, taps, *, Hj, Wj, isy, isx, osy=1, osx=1, ooy=0, oox=0,
+                 cout, cout_gemm, act=ACT_NONE, slope=0.2, resid=None,
+                 spade_x=None, mean=None, rstd=None, gamma_out=None):
+    d = C.ConvDesc()
+    d.in_, d.wt, d.out = inp.data_ptr(), wt.data_ptr(), out.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.resid = resid.data_ptr() if resid is not None else None
+    d.x = spade_x.data_ptr() if spade_x is not None else None
+    d.mean = mean.data_ptr() if mean is not None else None
+    d.rstd = rstd.data_ptr() if rstd is not None else None
+    d.gamma_out = gamma_out.data_ptr() if gamma_out is not None else None
+    d.dtype = _dt(inp)
+    d.N, d.Hin, d.Win, d.Cin = inp.shape
+    _, d.Hout, d.Wout, _ = out.shape
+    d.Cout, d.Cout_gemm, d.CoutP = cout, cout_gemm, wt.shape[1]
+    d.Hj, d.Wj, d.isy, d.isx = Hj, Wj, isy, isx
+    d.osy, d.osx, d.ooy, d.oox = osy, osx, ooy, oox
+    d.epilogue = C.MG_EPI_SPADE if spade_x is not None else C.MG_EPI_PLAIN
+    d.act, d.slope = act, slope
+    _set_taps(d, taps)
+    assert wt.shape[0] == len(taps) and wt.shape[2] == inp.shape[3] and wt.dtype == inp.dtype
+    C.backend().mg_conv_taps(d, _stream(inp))
+
+
+def _pack_rows(w: torch.Tensor, dtype, mult: int = 128) -> torch.Tensor:
+    """[T, R, K] fp32 -> [T, roundup(R, mult), K] in the compute dtype (zero rows appended)."""
+    r = w.shape[1]
+    rp = _roundup(r, mult)
+    w = w.detach()
+    if rp != r:
+        w = F.pad(w, (0, 0, 0, rp - r))
+    return w.to(dtype).contiguous()
+
+
+def _pack_bias(b: Optional[torch.Tensor], rows_p: int) -> Optional[torch.Tensor]:
+    if b is None:
+        return None
+    b = b.detach().float()
+    if b.numel() != rows_p:
+        b = F.pad(b, (0, rows_p - b.numel()))
+    return b.contiguous()
+
+
+def conv_dgrad(dy: torch.Tensor, wg: torch.Tensor, kh: int, kw: int, stride: int, pad: int,
+               in_hw: Tuple[int, int]) -> torch.Tensor:
+    """Data gradient of a forward conv whose GEMM-order weight is wg [T, Cg, Cin].
+
+    dy is [N, Ho, Wo, Cg8] (channels zero-padded to a multiple of 8).  For stride s the
+    output pixels split into s*s parity classes; each class is a stride-1 gather over
+    dy with the subset of taps whose offset is divisible by s (no wasted MACs).
+    """
+    n, ho, wo, cg8 = dy.shape
+    t, cg, cin = wg.shape
+    h, w = in_hw
+    wt = wg.detach().transpose(1, 2)                      # [T, Cin, Cg]
+    if cg8 != cg:
+        wt = F.pad(wt, (0, cg8 - cg))
+    wt = _pack_rows(wt, dy.dtype)                          # [T, CinP128, Cg8]
+    dx = (torch.zeros if stride > 1 else torch.empty)((n, h, w, cin), dtype=dy.dtype, device=dy.device)
+    for py in range(stride):
+        hj = len(range(py, h, stride))
+        for px in range(stride):
+            wj = len(range(px, w, stride))
+            if hj == 0 or wj == 0:
+                continue
+            taps, ids = [], []
+            for ky in range(kh):
+                if (py + pad - ky) % stride:
+                    continue
+                for kx in range(kw):
+                    if (px + pad - kx) % stride:
+                        continue
+                    taps.append(((py + pad - ky) // stride, (px + pad - kx) // stride))
+                    ids.append(ky * kw + kx)
+            if not taps:
+                continue
+            wcls = wt if len(ids) == t else wt[ids].contiguous()
+            _launch_conv(dy, wcls, dx, None, taps, Hj=hj, Wj=wj, isy=1, isx=1,
+                         osy=stride, osx=stride, ooy=py, oox=px, cout=cin, cout_gemm=cin)
+    return dx
+
+
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int, pad: int) -> torch.Tensor:
+    """dW in GEMM order [T, Cg8, Cin] (fp32) of a forward conv; split-K over pixels, fp32 atomics."""
+    n, h, w, cin = x.shape
+    _, hj, wj, cg8 = dy.shape
+    taps = fwd_taps(kh, kw, pad)
+    dw = torch.zeros((len(taps), cg8, cin), dtype=torch.float32, device=x.device)
+    d = C.WgradDesc()
+    d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
+    d.dtype = _dt(x)
+    d.N, d.Hin, d.Win, d.Cin = n, h, w, cin
+    d.Hj, d.Wj, d.Cg = hj, wj, cg8
+    d.isy = d.isx = stride
+    d.splitk = 0
+    d.flags = 1 if (WGRAD_USE_TR and x.dtype == torch.bfloat16) else 0
+    _set_taps(d, taps)
+    assert dy.dtype == x.dtype
+    C.backend().mg_conv_wgrad(d, _stream(x))
+    return dw
+
+
+def channel_sums(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
+    """x viewed as [G, P, C] -> fp32 [G, 2, C] (sum, sum of squares); deterministic two-stage reduce."""
+    c = x.shape[-1]
+    p = x.numel() // (groups * c)
+    be = C.backend()
+    ws = torch.empty(max(int(be.mg_stats_workspace(groups, p, c)), 4), dtype=torch.uint8, device=x.device)
+    sums = torch.empty((groups, 2, c), dtype=torch.float32, device=x.device)
+    be.mg_channel_stats(_p(x), _dt(x), groups, p, c, _p(sums), _p(ws), _stream(x))
+    return sums
+
+
+def act_backward(dy: torch.Tensor, y: torch.Tensor, act: int, slope: float) -> torch.Tensor:
+    if act == ACT_NONE:
+        return dy
+    dpre = torch.empty_like(dy)
+    numel = dy.numel()
+    if numel % 4:
+        raise ValueError("act_backward needs numel % 4 == 0")
+    C.backend().mg_act_bwd(_p(dy), _p(y), _p(dpre), _dt(dy), numel, act, slope, _stream(dy))
+    return dpre
+
+
+# ----------------------------------------------------------------------------
+# conv2d
+# ----------------------------------------------------------------------------
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wg, bias, resid, kh, kw, stride, pad, act, slope):
+        x = _nhwc(x)
+        n, h, w, cin = x.shape
+        t, cout, cin_w = wg.shape
+        if cin_w != cin or cin % 8:
+            raise ValueError(f"conv2d: input has {cin} channels, weight expects {cin_w} (must match, multiple of 8)")
+        ho = (h + 2 * pad - kh) // stride + 1
+        wo = (w + 2 * pad - kw) // stride + 1
+        wp = _pack_rows(wg, x.dtype)
+        bp = _pack_bias(bias, wp.shape[1])
+        out = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
+        if resid is not None:
+            resid = _nhwc(resid)
+            if resid.shape != out.shape or resid.dtype != out.dtype:
+                raise ValueError("conv2d: residual must match the output")
+        _launch_conv(x, wp, out, bp, fwd_taps(kh, kw, pad), Hj=ho, Wj=wo, isy=stride, isx=stride,
+                     cout=cout, cout_gemm=cout, act=act, slope=slope, resid=resid)
+        ctx.save_for_backward(x, wg, out if act != ACT_NONE else None)
+        ctx.cfg = (kh, kw, stride, pad, act, slope, bias is not None, resid is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wg, out = ctx.saved_tensors
+        kh, kw, stride, pad, act, slope, has_bias, has_resid = ctx.cfg
+        dout = dout.contiguous()
+        dpre = act_backward(dout, out, act, slope)
+        dpre8 = pad_channels(dpre, 8)
+        t, cout, cin = wg.shape
+        dx = dwg = dbias = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_dgrad(dpre8, wg, kh, kw, stride, pad, (x.shape[1], x.shape[2]))
+        if ctx.needs_input_grad[1]:
+            dwg = conv_wgrad(x, dpre8, kh, kw, stride, pad)[:, :cout, :]
+        if has_bias and ctx.needs_input_grad[2]:
+            dbias = channel_sums(dpre8)[0, 0, :cout]
+        dres = dpre if (has_resid and ctx.needs_input_grad[3]) else None
+        return dx, dwg, dbias, dres, None, None, None, None, None, None
+
+
+def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride: int = 1,
+           padding: int = 0, act: int = ACT_NONE, slope: float = 0.2,
+           resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NHWC convolution (+bias, +residual, +activation fused in the MFMA kernel's epilogue).
+
+    `weight` is the reference-layout fp32 parameter [Cout, Cin, kh, kw]; `x` may carry more
+    (zero) channels than Cin -- the weight is zero-padded to match.
+    """
+    cout, cin, kh, kw = weight.shape
+    if x.shape[-1] < cin:
+        raise ValueError(f"conv2d: input has {x.shape[-1]} channels < weight Cin {cin}")
+    x = pad_channels(x, 8)
+    wg = gemm_weight(weight.float(), x.shape[-1])
+    return _Conv2dFn.apply(x, wg, bias, resid, kh, kw, stride, padding, act, slope)
+
+
+# ----------------------------------------------------------------------------
+# batch statistics (sync-BN) and SPADE modulation
+# ----------------------------------------------------------------------------
+def batch_stats(x: torch.Tensor, eps: float = 1e-5):
+    """Per-channel batch statistics of an NHWC tensor over (N, H, W) [x all ranks of SYNC_BN_GROUP].
+
+    Returns (mean, rstd, unbiased_var, count); rstd = 1/sqrt(biased_var + eps) as F.batch_norm
+    computes it on one device (sync_batchnorm/batchnorm.py:65-68).  No autograd here: the
+    dependence of the statistics on x is handled inside the consumers' backward kernels.
+    """
+    with torch.no_grad():
+        x = _nhwc(x)
+        c = x.shape[-1]
+        count = x.numel() // c
+        sums = channel_sums(x)[0].double()                     # [2, C]
+        if SYNC_BN_GROUP is not None:
+            import torch.distributed as dist
+            packed = torch.cat([sums.reshape(-1), sums.new_tensor([float(count)])])
+            dist.all_reduce(packed, group=SYNC_BN_GROUP)
+            sums, count = packed[:-1].reshape(2, c), int(round(packed[-1].item()))
+        mean = sums[0] / count
+        var = (sums[1] / count - mean * mean).clamp_min_(0.0)
+        rstd = torch.rsqrt(var + eps)
+        unbiased = var * (count / max(count - 1, 1))
+        return mean.float(), rstd.float(), unbiased.float(), count
+
+
+def spade_gemm_weight(w_gamma: torch.Tensor, w_beta: torch.Tensor, b_gamma: torch.Tensor, b_beta: torch.Tensor,
+                      cin_pad: int):
+    """Interleave mlp_gamma / mlp_beta into the fused GEMM image: row blocks of 64 =
+    [32 gamma rows | 32 beta rows] of the same 32 output channels (differentiable)."""
+    c = w_gamma.shape[0]
+    cr = _roundup(c, 32)
+    gg, gb = gemm_weight(w_gamma.float(), cin_pad), gemm_weight(w_beta.float(), cin_pad)   # [T, C, K]
+    if cr != c:
+        gg, gb = F.pad(gg, (0, 0, 0, cr - c)), F.pad(gb, (0, 0, 0, cr - c))
+    t, _, k = gg.shape
+    wg = torch.stack([gg.reshape(t, cr // 32, 32, k), gb.reshape(t, cr // 32, 32, k)], dim=2).reshape(t, 2 * cr, k)
+    bg, bb = b_gamma.float(), b_beta.float()
+    if cr != c:
+        bg, bb = F.pad(bg, (0, cr - c)), F.pad(bb, (0, cr - c))
+    bias = torch.stack([bg.reshape(cr // 32, 32), bb.reshape(cr // 32, 32)], dim=1).reshape(2 * cr)
+    return wg, bias
+
+
+class _SpadeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, actv, wg, bias, mean, rstd, count, kh, pad, act, slope):
+        x, actv = _nhwc(x), _nhwc(actv)
+        n, h, w, c = x.shape
+        if actv.shape[:3] != x.shape[:3] or actv.dtype != x.dtype:
+            raise ValueError("spade_modulate: activation map and x disagree in shape/dtype")
+        t, rows, k = wg.shape
+        if rows != 2 * _roundup(c, 32) or k != actv.shape[-1]:
+            raise ValueError("spade_modulate: fused gamma/beta weight has the wrong shape")
+        wp = _pack_rows(wg, x.dtype)
+        bp = _pack_bias(bias, wp.shape[1])
+        out = torch.empty_like(x)
+        g1 = torch.empty_like(x)
+        _launch_conv(actv, wp, out, bp, fwd_taps(kh, kh, pad), Hj=h, Wj=w, isy=1, isx=1,
+                     cout=c, cout_gemm=rows, act=act, slope=slope,
+                     spade_x=x, mean=mean, rstd=rstd, gamma_out=g1)
+        ctx.save_for_backward(x, actv, wg, out, g1, mean, rstd)
+        ctx.cfg = (count, kh, pad, act, slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, actv, wg, h, g1, mean, rstd = ctx.saved_tensors
+        count, kh, pad, act, slope = ctx.cfg
+        dh = dh.contiguous()
+        n, hh, ww, c = x.shape
+        rows = wg.shape[1]
+        p = n * hh * ww
+        be = C.backend()
+        alloc = torch.zeros if rows != 2 * c else torch.empty      # padded gamma/beta rows must read 0
+        dgb = alloc((n, hh, ww, rows), dtype=x.dtype, device=x.device)
+        sums = torch.empty((1, 2, c), dtype=torch.float32, device=x.device)
+        ws = torch.empty(max(int(be.mg_stats_workspace(1, p, c)), 4), dtype=torch.uint8, device=x.device)
+        be.mg_norm_bwd_reduce(_p(dh), _p(h), _p(x), _p(g1), _dt(x), 1, p, c, _p(mean), _p(rstd), act, slope,
+                              _p(dgb), _p(sums), _p(ws), _stream(x))
+        dx = dactv = dwg = dbias = None
+        if ctx.needs_input_grad[0]:
+            if SYNC_BN_GROUP is not None:
+                import torch.distributed as dist
+                dist.all_reduce(sums, group=SYNC_BN_GROUP)
+            s = (sums[0] / float(count)).contiguous()
+            dx = torch.empty_like(x)
+            be.mg_norm_bwd_apply(_p(dh), _p(h), _p(x), _p(g1), _dt(x), 1, p, c, _p(mean), _p(rstd),
+                                 _p(s[0]), _p(s[1]), act, slope, _p(dx), _stream(x))
+        if ctx.needs_input_grad[1]:
+            dactv = conv_dgrad(dgb, wg, kh, kh, 1, pad, (hh, ww))
+        if ctx.needs_input_grad[2]:
+            dwg = conv_wgrad(actv, dgb, kh, kh, 1, pad)
+        if ctx.needs_input_grad[3]:
+            dbias = channel_sums(dgb)[0, 0]
+        return dx, dactv, dwg, dbias, None, None, None, None, None, None, None
+
+
+def spade_modulate(x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, *, act=ACT_NONE, slope=0.2):
+    """h = act( (x - mean) * rstd * (1 + conv(actv, Wg) + bg) + conv(actv, Wb) + bb ), one MFMA launch.
+
+    gamma and beta are produced and consumed in registers (normalization.py:111-116 writes
+    both to memory and makes ~12 elementwise passes).  The backward implements the full
+    batch-norm gradient (statistics included), so `mean`/`rstd` enter as constants.
+    """
+    kh = w_gamma.shape[2]
+    wg, bias = spade_gemm_weight(w_gamma, w_beta, b_gamma, b_beta, actv.shape[-1])
+    return _SpadeFn.apply(x, actv, wg, bias, mean, rstd, count, kh, kh // 2, act, slope)
+
+
+# ----------------------------------------------------------------------------
+# instance norm (+ activation)
+# ----------------------------------------------------------------------------
+class _InstanceNormActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps, act, slope):
+        x = _nhwc(x)
+        n, h, w, c = x.shape
+        p = h * w
+        sums = channel_sums(x, groups=n).double()
+        mean = sums[:, 0] / p
+        var = (sums[:, 1] / p - mean * mean).clamp_min_(0.0)
+        rstd = torch.rsqrt(var + eps).float().contiguous()
+        mean = mean.float().contiguous()
+        y = torch.empty_like(x)
+        C.backend().mg_norm_act_fwd(_p(x), _p(y), _dt(x), n, p, c, _p(mean), _p(rstd), act, slope, _stream(x))
+        ctx.save_for_backward(x, y, mean, rstd)
+        ctx.cfg = (act, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, rstd = ctx.saved_tensors
+        act, slope = ctx.cfg
+        dy = dy.contiguous()
+        n, h, w, c = x.shape
+        p = h * w
+        be = C.backend()
+        sums = torch.empty((n, 2, c), dtype=torch.float32, device=x.device)
+        ws = torch.empty(max(int(be.mg_stats_workspace(n, p, c)), 4), dtype=torch.uint8, device=x.device)
+        be.mg_norm_bwd_reduce(_p(dy), _p(y), _p(x), None, _dt(x), n, p, c, _p(mean), _p(rstd), act, slope,
+                              None, _p(sums), _p(ws), _stream(x))
+        s1 = (sums[:, 0] / p).contiguous()
+        s2 = (sums[:, 1] / p).contiguous()
+        dx = torch.empty_like(x)
+        be.mg_norm_bwd_apply(_p(dy), _p(y), _p(x), None, _dt(x), n, p, c, _p(mean), _p(rstd), _p(s1), _p(s2),
+                             act, slope, _p(dx), _stream(x))
+        return dx, None, None, None
+
+
+def instance_norm_act(x, *, eps: float = 1e-5, act: int = ACT_NONE, slope: float = 0.2):
+    """nn.InstanceNorm2d(affine=False) followed by an optional fused activation (NHWC)."""
+    return _InstanceNormActFn.apply(x, eps, act, slope)
+
+
+# ----------------------------------------------------------------------------
+# resampling / pooling / blending
+# ----------------------------------------------------------------------------
+def _geom(x):
+    n, h, w, c = x.shape
+    if c % 4:
+        raise ValueError(f"NHWC streaming kernels need C % 4 == 0, got {c}")
+    return n, h, w, c
+
+
+class _Up2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _nhwc(x)
+        n, h, w, c = _geom(x)
+        y = torch.empty((n, 2 * h, 2 * w, c), dtype=x.dtype, device=x.device)
+        C.backend().mg_upsample2x_fwd(_p(x), _p(y), _dt(x), n, h, w, c, _stream(x))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        n, h2, w2, c = dy.shape
+        dx = torch.empty((n, h2 // 2, w2 // 2, c), dtype=dy.dtype, device=dy.device)
+        C.backend().mg_upsample2x_bwd(_p(dy), _p(dx), _dt(dy), n, h2 // 2, w2 // 2, c, _stream(dy))
+        return dx
+
+
+class _AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _nhwc(x)
+        n, h, w, c = _geom(x)
+        y = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=x.dtype, device=x.device)
+        C.backend().mg_avgpool3s2_fwd(_p(x), _p(y), _dt(x), n, h, w, c, _stream(x))
+        ctx.hw = (h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        h, w = ctx.hw
+        n, _, _, c = dy.shape
+        dx = torch.empty((n, h, w, c), dtype=dy.dtype, device=dy.device)
+        C.backend().mg_avgpool3s2_bwd(_p(dy), _p(dx), _dt(dy), n, h, w, c, _stream(dy))
+        return dx
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _nhwc(x)
+        n, h, w, c = _geom(x)
+        y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
+        C.backend().mg_maxpool2_fwd(_p(x), _p(y), _dt(x), n, h, w, c, _stream(x))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, h, w, c = x.shape
+        dx = torch.empty_like(x)
+        C.backend().mg_maxpool2_bwd(_p(dy), _p(x), _p(dx), _dt(x), n, h, w, c, _stream(x))
+        return dx
+
+
+class _BlendFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, bg, x, hair, back):
+        bg, x = _nhwc(bg), _nhwc(x)
+        if bg.shape != x.shape or bg.dtype != x.dtype:
+            raise ValueError("blend: background features and x disagree")
+        n, h, w, c = _geom(x)
+        hair = hair.reshape(-1).float().contiguous()
+        back = back.reshape(-1).float().contiguous()
+        if hair.numel() != n * h * w or back.numel() != n * h * w:
+            raise ValueError("blend: masks must have one value per pixel")
+        y = torch.empty_like(x)
+        C.backend().mg_blend_fwd(_p(bg), _p(x), _p(hair), _p(back), _p(y), _dt(x), n * h * w, c, _stream(x))
+        ctx.save_for_backward(hair, back)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        hair, back = ctx.saved_tensors
+        dy = dy.contiguous()
+        c = dy.shape[-1]
+        p = dy.numel() // c
+        dbg = torch.empty_like(dy) if ctx.needs_input_grad[0] else None
+        dx = torch.empty_like(dy) if ctx.needs_input_grad[1] else None
+        if dbg is not None or dx is not None:
+            C.backend().mg_blend_bwd(_p(dy), _p(hair), _p(back), _p(dbg), _p(dx), _dt(dy), p, c, _stream(dy))
+        return dbg, dx, None, None
+
+
+def upsample2x(x):
+    """nn.Upsample(scale_factor=2, mode='nearest') on NHWC."""
+    return _Up2Fn.apply(x)
+
+
+def avgpool3s2(x):
+    """F.avg_pool2d(k=3, s=2, p=1, count_include_pad=False) on NHWC."""
+    return _AvgPoolFn.apply(x)
+
+
+def maxpool2(x):
+    """nn.MaxPool2d(2, 2) on NHWC."""
+    return _MaxPoolFn.apply(x)
+
+
+def blend(bg, x, hair_mask, back_mask):
+    """bg * (1 - hair_mask) + x * (1 - back_mask); masks are per-pixel (N*H*W values)."""
+    return _BlendFn.apply(bg, x, hair_mask, back_mask)
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, *, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    """In-place fused Adam on flat fp32 buffers (torch.optim.Adam semantics)."""
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("adam_step wants contiguous fp32 buffers")
+    C.backend().mg_adam_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(),
+                             lr, beta1, beta2, eps, step, grad_scale, _stream(param))
+
+
+# NCHW <-> NHWC glue for module boundaries (zero-copy when the tensor is already channels_last)
+def to_nhwc(x: torch.Tensor, dtype=None) -> torch.Tensor:
+    y = x.permute(0, 2, 3, 1)
+    if dtype is not None and y.dtype != dtype:
+        y = y.to(dtype)
+    return y.contiguous()
+
+
+def to_nchw(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(0, 3, 1, 2)

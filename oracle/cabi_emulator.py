@@ -1,0 +1,303 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the C-ABI *contract* of
+libmichigan_hip.so (include/michigan_hip.h), entry point by entry point.
+
+Two uses, both from ``tests/`` only:
+  * ``-m "not gpu"`` tests install it with ``michigan_amd._cabi.set_backend`` so the
+    whole host stack (weight packing, dgrad parity decomposition, SPADE backward,
+    module graphs, the gloo data-parallel path) runs here and is checked against
+    the reference-derived oracle (oracle/michigan_oracle.py);
+  * ``-m gpu`` tests run the real HIP kernels and this emulator on the same raw
+    buffers and compare them (per-kernel contract parity).
+
+It works on host memory through the same raw pointers the kernels get (ctypes
+``from_address``), computes in float64 and rounds once to the storage dtype.  The
+product never imports this module; michigan_amd has no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+
+MG_F32, MG_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+_TD = {MG_F32: torch.float32, MG_BF16: torch.bfloat16}
+
+
+def _addr(p):
+    if p is None:
+        return 0
+    if isinstance(p, ctypes.c_void_p):
+        return p.value or 0
+    return int(p)
+
+
+def _view(p, shape, dtype):
+    """A torch tensor aliasing host memory at raw address p."""
+    addr = _addr(p)
+    if addr == 0:
+        return None
+    n = 1
+    for s in shape:
+        n *= int(s)
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    buf = (ctypes.c_char * nbytes).from_address(addr)
+    return torch.frombuffer(buf, dtype=dtype, count=n).view(*[int(s) for s in shape])
+
+
+def _act(v, act, slope):
+    if act == ACT_RELU:
+        return torch.clamp_min(v, 0)
+    if act == ACT_LRELU:
+        return torch.where(v > 0, v, v * slope)
+    if act == ACT_TANH:
+        return torch.tanh(v)
+    return v
+
+
+def _act_grad_from_out(y, act, slope):
+    if act == ACT_RELU:
+        return (y > 0).to(y.dtype)
+    if act == ACT_LRELU:
+        return torch.where(y > 0, torch.ones_like(y), torch.full_like(y, slope))
+    if act == ACT_TANH:
+        return 1 - y * y
+    return torch.ones_like(y)
+
+
+def _gather(x, hj, wj, isy, isx, dy, dx):
+    """x [N,H,W,C] -> [N,hj,wj,C]: x[n, j*is + d] with zeros outside."""
+    n, h, w, c = x.shape
+    iy = torch.arange(hj) * isy + dy
+    ix = torch.arange(wj) * isx + dx
+    vy = (iy >= 0) & (iy < h)
+    vx = (ix >= 0) & (ix < w)
+    g = x[:, iy.clamp(0, h - 1)][:, :, ix.clamp(0, w - 1)]
+    return g * (vy[:, None] & vx[None, :]).to(x.dtype)[None, :, :, None]
+
+
+class EmulatorBackend:
+    name = "emulator"
+
+    # -- bookkeeping ---------------------------------------------------------
+    def mg_abi_version(self):
+        return 1
+
+    def mg_sizeof_desc(self, which):
+        from michigan_amd import _cabi
+        return ctypes.sizeof(_cabi.ConvDesc if which == 0 else _cabi.WgradDesc)
+
+    def mg_last_error(self):
+        return b""
+
+    # -- conv ------------------------------------------------------------------
+    def mg_conv_taps(self, d, stream=None):
+        td = _TD[d.dtype]
+        x = _view(d.in_, (d.N, d.Hin, d.Win, d.Cin), td).double()
+        w = _view(d.wt, (d.ntaps, d.CoutP, d.Cin), td).double()
+        out = _view(d.out, (d.N, d.Hout, d.Wout, d.Cout), td)
+        acc = torch.zeros((d.N, d.Hj, d.Wj, d.Cout_gemm), dtype=torch.float64)
+        for t in range(d.ntaps):
+            g = _gather(x, d.Hj, d.Wj, d.isy, d.isx, int(d.tap_dy[t]), int(d.tap_dx[t]))
+            acc += g @ w[t, :d.Cout_gemm].t()
+        if _addr(d.bias):
+            acc += _view(d.bias, (d.CoutP,), torch.float32).double()[:d.Cout_gemm]
+        oy = slice(d.ooy, d.ooy + (d.Hj - 1) * d.osy + 1, d.osy)
+        ox = slice(d.oox, d.oox + (d.Wj - 1) * d.osx + 1, d.osx)
+        if d.epilogue == 0:
+            v = acc[..., :d.Cout]
+            if _addr(d.resid):
+                v = v + _view(d.resid, (d.N, d.Hout, d.Wout, d.Cout), td).double()[:, oy, ox]
+            out[:, oy, ox] = _act(v, d.act, d.slope).to(td)
+        else:
+            c = d.Cout
+            ch = torch.arange(c)
+            rg = 64 * (ch // 32) + ch % 32
+            g1 = 1.0 + acc[..., rg]
+            beta = acc[..., rg + 32]
+            xs = _view(d.x, (d.N, d.Hout, d.Wout, c), td).double()[:, oy, ox]
+            mean = _view(d.mean, (c,), torch.float32).double()
+            rstd = _view(d.rstd, (c,), torch.float32).double()
+            pre = (xs - mean) * rstd * g1 + beta
+            out[:, oy, ox] = _act(pre, d.act, d.slope).to(td)
+            if _addr(d.gamma_out):
+                _view(d.gamma_out, (d.N, d.Hout, d.Wout, c), td)[:, oy, ox] = g1.to(td)
+        return 0
+
+    def mg_conv_wgrad(self, d, stream=None):
+        td = _TD[d.dtype]
+        x = _view(d.x, (d.N, d.Hin, d.Win, d.Cin), td).double()
+        dy = _view(d.dy, (d.N, d.Hj, d.Wj, d.Cg), td).double().reshape(-1, d.Cg)
+        dw = _view(d.dw, (d.ntaps, d.Cg, d.Cin), torch.float32)
+        for t in range(d.ntaps):
+            g = _gather(x, d.Hj, d.Wj, d.isy, d.isx, int(d.tap_dy[t]), int(d.tap_dx[t])).reshape(-1, d.Cin)
+            dw[t] += (dy.t() @ g).float()
+        return 0
+
+    # -- statistics / norms ------------------------------------------------------
+    def mg_stats_workspace(self, G, P, C):
+        return 16
+
+    def mg_channel_stats(self, x, dtype, G, P, C, sums, partial, stream=None):
+        xv = _view(x, (G, P, C), _TD[dtype]).double()
+        s = _view(sums, (G, 2, C), torch.float32)
+        s[:, 0] = xv.sum(1).float()
+        s[:, 1] = (xv * xv).sum(1).float()
+        return 0
+
+    def mg_norm_act_fwd(self, x, y, dtype, G, P, C, mean, rstd, act, slope, stream=None):
+        td = _TD[dtype]
+        xv = _view(x, (G, P, C), td).double()
+        mu = _view(mean, (G, 1, C), torch.float32).double()
+        rs = _view(rstd, (G, 1, C), torch.float32).double()
+        _view(y, (G, P, C), td)[:] = _act((xv - mu) * rs, act, slope).to(td)
+        return 0
+
+    def _bwd_common(self, dh, h, x, g1, dtype, G, P, C, mean, rstd, act, slope):
+        td = _TD[dtype]
+        dhv = _view(dh, (G, P, C), td).double()
+        hv = _view(h, (G, P, C), td).double()
+        xv = _view(x, (G, P, C), td).double()
+        mu = _view(mean, (G, 1, C), torch.float32).double()
+        rs = _view(rstd, (G, 1, C), torch.float32).double()
+        dpre = dhv * _act_grad_from_out(hv, act, slope)
+        xh = (xv - mu) * rs
+        g1v = _view(g1, (G, P, C), td)
+        dxh = dpre * g1v.double() if g1v is not None else dpre
+        return dpre, xh, dxh, rs
+
+    def mg_norm_bwd_reduce(self, dh, h, x, g1, dtype, G, P, C, mean, rstd, act, slope, dgb, sums, partial, stream=None):
+        dpre, xh, dxh, _ = self._bwd_common(dh, h, x, g1, dtype, G, P, C, mean, rstd, act, slope)
+        s = _view(sums, (G, 2, C), torch.float32)
+        s[:, 0] = dxh.sum(1).float()
+        s[:, 1] = (dxh * xh).sum(1).float()
+        if _addr(dgb):
+            td = _TD[dtype]
+            cr2 = 2 * ((C + 31) // 32) * 32
+            out = _view(dgb, (P, cr2), td)
+            ch = torch.arange(C)
+            rg = 64 * (ch // 32) + ch % 32
+            out[:, rg] = (dpre[0] * xh[0]).to(td)
+            out[:, rg + 32] = dpre[0].to(td)
+        return 0
+
+    def mg_norm_bwd_apply(self, dh, h, x, g1, dtype, G, P, C, mean, rstd, s1, s2, act, slope, dx, stream=None):
+        _, xh, dxh, rs = self._bwd_common(dh, h, x, g1, dtype, G, P, C, mean, rstd, act, slope)
+        a = _view(s1, (G, 1, C), torch.float32).double()
+        b = _view(s2, (G, 1, C), torch.float32).double()
+        td = _TD[dtype]
+        _view(dx, (G, P, C), td)[:] = (rs * (dxh - a - xh * b)).to(td)
+        return 0
+
+    def mg_act_bwd(self, dy, y, dpre, dtype, numel, act, slope, stream=None):
+        td = _TD[dtype]
+        d = _view(dy, (numel,), td).double()
+        v = _view(y, (numel,), td).double()
+        _view(dpre, (numel,), td)[:] = (d * _act_grad_from_out(v, act, slope)).to(td)
+        return 0
+
+    # -- resampling ----------------------------------------------------------------
+    def mg_upsample2x_fwd(self, x, y, dtype, N, H, W, C, stream=None):
+        td = _TD[dtype]
+        xv = _view(x, (N, H, W, C), td)
+        _view(y, (N, 2 * H, 2 * W, C), td)[:] = xv.repeat_interleave(2, 1).repeat_interleave(2, 2)
+        return 0
+
+    def mg_upsample2x_bwd(self, dy, dx, dtype, N, H, W, C, stream=None):
+        td = _TD[dtype]
+        d = _view(dy, (N, H, 2, W, 2, C), td).double()
+        _view(dx, (N, H, W, C), td)[:] = d.sum((2, 4)).to(td)
+        return 0
+
+    @staticmethod
+    def _pool_cnt(L, Lo):
+        o = torch.arange(Lo)
+        lo = (2 * o - 1).clamp_min(0)
+        hi = (2 * o + 1).clamp_max(L - 1)
+        return (hi - lo + 1).double()
+
+    def mg_avgpool3s2_fwd(self, x, y, dtype, N, H, W, C, stream=None):
+        td = _TD[dtype]
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        xv = _view(x, (N, H, W, C), td).double()
+        s = torch.zeros((N, Ho, Wo, C), dtype=torch.float64)
+        for ky in (-1, 0, 1):
+            for kx in (-1, 0, 1):
+                s += _gather(xv, Ho, Wo, 2, 2, ky, kx)
+        cnt = self._pool_cnt(H, Ho)[:, None] * self._pool_cnt(W, Wo)[None, :]
+        _view(y, (N, Ho, Wo, C), td)[:] = (s / cnt[None, :, :, None]).to(td)
+        return 0
+
+    def mg_avgpool3s2_bwd(self, dy, dx, dtype, N, H, W, C, stream=None):
+        td = _TD[dtype]
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        d = _view(dy, (N, Ho, Wo, C), td).double()
+        cnt = self._pool_cnt(H, Ho)[:, None] * self._pool_cnt(W, Wo)[None, :]
+        d = d / cnt[None, :, :, None]
+        out = torch.zeros((N, H + 2, W + 2, C), dtype=torch.float64)
+        for ky in (-1, 0, 1):
+            for kx in (-1, 0, 1):
+                out[:, 1 + ky:1 + ky + 2 * Ho:2, 1 + kx:1 + kx + 2 * Wo:2][:, :Ho, :Wo] += d
+        _view(dx, (N, H, W, C), td)[:] = out[:, 1:H + 1, 1:W + 1].to(td)
+        return 0
+
+    def mg_maxpool2_fwd(self, x, y, dtype, N, H, W, C, stream=None):
+        td = _TD[dtype]
+        Ho, Wo = H // 2, W // 2
+        xv = _view(x, (N, H, W, C), td)[:, :2 * Ho, :2 * Wo].reshape(N, Ho, 2, Wo, 2, C)
+        _view(y, (N, Ho, Wo, C), td)[:] = xv.amax((2, 4))
+        return 0
+
+    def mg_maxpool2_bwd(self, dy, x, dx, dtype, N, H, W, C, stream=None):
+        td = _TD[dtype]
+        Ho, Wo = H // 2, W // 2
+        xv = _view(x, (N, H, W, C), td).float()[:, :2 * Ho, :2 * Wo].reshape(N, Ho, 2, Wo, 2, C)
+        win = xv.permute(0, 1, 3, 5, 2, 4).reshape(N, Ho, Wo, C, 4)
+        # first maximum in window scan order (ATen max_pool2d picks the first with val > max)
+        arg = torch.zeros((N, Ho, Wo, C), dtype=torch.long)
+        best = win[..., 0].clone()
+        for k in range(1, 4):
+            better = win[..., k] > best
+            best = torch.where(better, win[..., k], best)
+            arg = torch.where(better, torch.full_like(arg, k), arg)
+        d = _view(dy, (N, Ho, Wo, C), td).float()
+        g = torch.zeros((N, Ho, Wo, C, 4))
+        g.scatter_(4, arg[..., None], d[..., None])
+        full = torch.zeros((N, H, W, C))
+        full[:, :2 * Ho, :2 * Wo] = g.reshape(N, Ho, Wo, C, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(N, 2 * Ho, 2 * Wo, C)
+        _view(dx, (N, H, W, C), td)[:] = full.to(td)
+        return 0
+
+    def mg_blend_fwd(self, bg, x, hair, back, y, dtype, P, C, stream=None):
+        td = _TD[dtype]
+        b = _view(bg, (P, C), td).double()
+        v = _view(x, (P, C), td).double()
+        hm = _view(hair, (P, 1), torch.float32).double()
+        bm = _view(back, (P, 1), torch.float32).double()
+        _view(y, (P, C), td)[:] = (b * (1 - hm) + v * (1 - bm)).to(td)
+        return 0
+
+    def mg_blend_bwd(self, dy, hair, back, dbg, dx, dtype, P, C, stream=None):
+        td = _TD[dtype]
+        d = _view(dy, (P, C), td).double()
+        hm = _view(hair, (P, 1), torch.float32).double()
+        bm = _view(back, (P, 1), torch.float32).double()
+        if _addr(dbg):
+            _view(dbg, (P, C), td)[:] = (d * (1 - hm)).to(td)
+        if _addr(dx):
+            _view(dx, (P, C), td)[:] = (d * (1 - bm)).to(td)
+        return 0
+
+    def mg_adam_step(self, param, grad, m, v, numel, lr, b1, b2, eps, step, gscale, stream=None):
+        p = _view(param, (numel,), torch.float32)
+        g = _view(grad, (numel,), torch.float32) * gscale
+        mm = _view(m, (numel,), torch.float32)
+        vv = _view(v, (numel,), torch.float32)
+        mm.lerp_(g, 1 - b1)
+        vv.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1 = 1 - b1 ** step
+        bc2 = 1 - b2 ** step
+        denom = vv.sqrt() / math.sqrt(bc2) + eps
+        p.addcdiv_(mm, denom, value=-lr / bc1)
+        return 0

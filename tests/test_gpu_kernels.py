@@ -1,0 +1,283 @@
+"""-m gpu: every HIP entry point, called through the C ABI / op layer, against the
+contract emulator (oracle/cabi_emulator.py) on identical inputs.
+
+Tolerances (stated per dtype):
+  f32  : |hip - ref| <= 2e-5 * max|ref|   (fp32 MFMA = exact fma chain; only the
+         summation order differs from the float64 emulator)
+  bf16 : |hip - ref| <= 2^-7 * max|ref|   (one bf16 ulp at the top of the range:
+         both sides round an fp32/fp64 accumulation to bf16 once)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+TOL = {"f32": 2e-5, "bf16": 2.0 ** -7}
+
+
+def _close(name, got, ref, tol):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    err = (got - ref).abs().max().item()
+    scale = max(ref.abs().max().item(), 1e-6)
+    assert np.isfinite(err) and err <= tol * scale, f"{name}: max err {err:.3e} > {tol:.1e} * {scale:.3e}"
+
+
+def _both(fn, tensors, grads_of=()):
+    """Run fn on cuda tensors with the HIP backend and on cpu copies with the emulator."""
+    from michigan_amd import _cabi
+    from oracle.cabi_emulator import EmulatorBackend
+    outs = []
+    dry = os.environ.get("MG_TEST_DRYRUN") == "1"       # CPU-only plumbing check of this file (emulator both sides)
+    for dev, be in (("cpu" if dry else "cuda", EmulatorBackend() if dry else None), ("cpu", EmulatorBackend())):
+        prev = _cabi.set_backend(be)
+        try:
+            if be is None:
+                assert _cabi.backend().name == "hip"
+            args = [t.detach().to(dev).requires_grad_(t.requires_grad) if torch.is_tensor(t) else t for t in tensors]
+            res = fn(*args)
+            if dev == "cuda":
+                torch.cuda.synchronize()
+            outs.append((res, args))
+        finally:
+            _cabi.set_backend(prev)
+    return outs
+
+
+def test_probe_mfma_fragment_layout(hip_backend):
+    out = torch.zeros(3, 64, 16, device="cuda")
+    hip_backend.mg_probe_mfma_layout(out.data_ptr(), None)
+    torch.cuda.synchronize()
+    out = out.cpu()
+    lane = torch.arange(64)[:, None]
+    reg = torch.arange(16)[None, :]
+    row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)          # C/D row held by (lane, reg)
+    col = (lane & 31).expand(64, 16)
+    assert torch.equal(out[0], row.float()), "bf16 32x32x16: A row != lane&31 or C/D row map differs"
+    assert torch.equal(out[1], col.float()), "bf16 32x32x16: B col != lane&31 or C/D col map differs"
+    assert torch.equal(out[2], row.float()), "f32 32x32x2: fragment map differs"
+
+
+def test_probe_ds_read_tr16(hip_backend):
+    src = torch.arange(256, dtype=torch.int16, device="cuda")
+    dst = torch.zeros(256, dtype=torch.int16, device="cuda")
+    hip_backend.mg_probe_tr16(src.data_ptr(), dst.data_ptr(), None)
+    torch.cuda.synchronize()
+    got = dst.cpu().view(64, 4)
+    m = src.cpu().view(4, 16, 4)                               # [group][lane i][elem e]
+    l = torch.arange(16)
+    exp = torch.stack([torch.stack([m[g, 4 * j + (l >> 2), l & 3] for j in range(4)], dim=1) for g in range(4)]).view(64, 4)
+    assert torch.equal(got, exp), f"ds_read_b64_tr_b16 map differs from the assumed one:\n{got[:16]}"
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, H, W, N
+    (128, 128, 3, 1, 1, 24, 20, 2),     # 128x128 tile, full K chunks
+    (64, 64, 3, 1, 1, 33, 17, 1),       # 64x256 tile
+    (48, 200, 3, 1, 1, 9, 13, 2),       # K tail (48 = 32 + 16), ragged Cout
+    (4, 128, 3, 1, 1, 16, 16, 2),       # tiny Cin (SPADE mlp_shared)
+    (64, 3, 3, 1, 1, 20, 20, 2),        # Cout 3 (conv_img), 32-row tile, scalar stores
+    (7, 64, 4, 2, 2, 21, 19, 2),        # D layer 0: 4x4 s2 p2, odd size
+    (64, 128, 4, 2, 2, 17, 17, 2),      # D s2
+    (256, 512, 4, 1, 2, 10, 9, 1),      # D s1 p2
+    (512, 1, 4, 1, 2, 9, 9, 2),         # D head
+    (3, 64, 7, 1, 0, 22, 22, 1),        # 7x7 (background encoder, pre-padded)
+    (64, 128, 4, 2, 0, 18, 18, 1),      # 4x4 s2 on reflect-padded input
+    (24, 40, 3, 2, 1, 16, 16, 2),       # partial-conv trunk 3x3 s2
+    (1024, 512, 1, 1, 0, 8, 8, 2),      # conv_s 1x1
+]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_fwd_bwd(case, dt):
+    from michigan_amd import ops
+    cin, cout, k, s, p, H, W, N = case
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(N, H, W, cin, generator=g).to(DT[dt]).requires_grad_()
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).requires_grad_()
+    b = torch.randn(cout, generator=g).requires_grad_()
+
+    def fn(x, w, b):
+        y = ops.conv2d(x, w, b, stride=s, padding=p, act=ops.ACT_LRELU)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(7)).to(y.dtype).to(y.device)
+        gx, gw, gb = torch.autograd.grad(y, (x, w, b), gy)
+        return y, gx, gw, gb
+
+    (hip, _), (ref, _) = _both(fn, (x, w, b))
+    for name, a, r in zip(("y", "dx", "dw", "db"), hip, ref):
+        _close(f"conv {case} {dt} {name}", a, r, TOL[dt] * (4 if name in ("dw", "db") and dt == "bf16" else 1))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv2d_residual_and_tanh(dt):
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 12, 12, 64, generator=g).to(DT[dt]).requires_grad_()
+    r = torch.randn(2, 12, 12, 96, generator=g).to(DT[dt]).requires_grad_()
+    w = (torch.randn(96, 64, 3, 3, generator=g) / 24).requires_grad_()
+
+    def fn(x, r, w):
+        y = ops.conv2d(x, w, None, padding=1, resid=r)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(y.dtype).to(y.device)
+        gx, gr, gw = torch.autograd.grad(y, (x, r, w), gy)
+        return y, gx, gr, gw
+
+    (hip, _), (ref, _) = _both(fn, (x, r, w))
+    for name, a, rr in zip(("y", "dx", "dres", "dw"), hip, ref):
+        _close(f"resid {dt} {name}", a, rr, TOL[dt] * (4 if name == "dw" and dt == "bf16" else 1))
+
+    def fn2(x, w3):
+        y = ops.conv2d(x, w3, None, padding=1, act=ops.ACT_TANH)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).to(y.dtype).to(y.device)
+        gx, gw = torch.autograd.grad(y, (x, w3), gy)
+        return y, gx, gw
+    w3 = (torch.randn(3, 64, 3, 3, generator=g) / 24).requires_grad_()
+    (hip, _), (ref, _) = _both(fn2, (x, w3))
+    for name, a, rr in zip(("y", "dx", "dw"), hip, ref):
+        _close(f"tanh {dt} {name}", a, rr, TOL[dt] * (4 if name == "dw" and dt == "bf16" else 1))
+
+
+@pytest.mark.parametrize("tr", [True, False], ids=["tr16", "gather"])
+def test_wgrad_bf16_both_fragment_paths(tr):
+    from michigan_amd import ops
+    old = ops.WGRAD_USE_TR
+    ops.WGRAD_USE_TR = tr
+    try:
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(2, 19, 23, 136, generator=g).bfloat16()
+        dy = torch.randn(2, 19, 23, 200, generator=g).bfloat16()
+
+        def fn(x, dy):
+            return (ops.conv_wgrad(x, dy, 3, 3, 1, 1),)
+        (hip, _), (ref, _) = _both(fn, (x, dy))
+        _close(f"wgrad tr={tr}", hip[0], ref[0], 2e-3)
+    finally:
+        ops.WGRAD_USE_TR = old
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("C,H,W", [(64, 20, 24), (32, 16, 16), (48, 9, 11), (256, 8, 8), (16, 12, 12)])
+def test_spade_modulate_fwd_bwd(C, H, W, dt):
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(2, H, W, C, generator=g) * 1.5 + 0.3).to(DT[dt]).requires_grad_()
+    actv = torch.randn(2, H, W, 128, generator=g).clamp_min(0).to(DT[dt]).requires_grad_()
+    wg = (torch.randn(C, 128, 3, 3, generator=g) / 34).requires_grad_()
+    wb = (torch.randn(C, 128, 3, 3, generator=g) / 34).requires_grad_()
+    bg = (torch.randn(C, generator=g) * 0.1).requires_grad_()
+    bb = (torch.randn(C, generator=g) * 0.1).requires_grad_()
+
+    def fn(x, actv, wg, bg, wb, bb):
+        mean, rstd, unb, cnt = ops.batch_stats(x)
+        h = ops.spade_modulate(x, actv, wg, bg, wb, bb, mean, rstd, cnt, act=ops.ACT_LRELU)
+        gh = torch.randn(h.shape, generator=torch.Generator().manual_seed(9)).to(h.dtype).to(h.device)
+        grads = torch.autograd.grad(h, (x, actv, wg, bg, wb, bb), gh)
+        return (h, mean, rstd) + grads
+
+    (hip, _), (ref, _) = _both(fn, (x, actv, wg, bg, wb, bb))
+    names = ("h", "mean", "rstd", "dx", "dactv", "dwg", "dbg", "dwb", "dbb")
+    for name, a, r in zip(names, hip, ref):
+        loose = dt == "bf16" and name in ("dx", "dactv", "dwg", "dbg", "dwb", "dbb")
+        _close(f"spade C={C} {dt} {name}", a, r, TOL[dt] * (6 if loose else 1) if name not in ("mean", "rstd") else 1e-5)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_channel_stats_wide_and_grouped(dt):
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(2)
+    for shape, groups in (((1, 37, 29, 2048), 1), ((3, 33, 17, 128), 3), ((2, 129, 129, 64), 2), ((8, 8, 8, 1024), 1)):
+        x = (torch.randn(shape, generator=g) + 0.5).to(DT[dt])
+
+        def fn(x):
+            return (ops.channel_sums(x, groups),)
+        (hip, _), (ref, _) = _both(fn, (x,))
+        _close(f"stats {shape} g={groups} {dt}", hip[0], ref[0], 1e-5)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_instance_norm_act(dt):
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(4, 33, 35, 128, generator=g) * 2 + 1).to(DT[dt]).requires_grad_()
+
+    def fn(x):
+        y = ops.instance_norm_act(x, act=ops.ACT_LRELU)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(6)).to(y.dtype).to(y.device)
+        (gx,) = torch.autograd.grad(y, x, gy)
+        return y, gx
+    (hip, _), (ref, _) = _both(fn, (x,))
+    _close(f"inorm {dt} y", hip[0], ref[0], TOL[dt])
+    _close(f"inorm {dt} dx", hip[1], ref[1], TOL[dt] * 2)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("op", ["upsample2x", "avgpool3s2", "maxpool2"])
+def test_resampling(op, dt):
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 17, 21, 24, generator=g).to(DT[dt]).requires_grad_()
+
+    def fn(x):
+        y = getattr(ops, op)(x)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).to(y.dtype).to(y.device)
+        (gx,) = torch.autograd.grad(y, x, gy)
+        return y, gx
+    (hip, _), (ref, _) = _both(fn, (x,))
+    _close(f"{op} {dt} y", hip[0], ref[0], TOL[dt])
+    _close(f"{op} {dt} dx", hip[1], ref[1], TOL[dt])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_blend_and_adam(dt):
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(10)
+    bgf = torch.randn(2, 9, 9, 64, generator=g).to(DT[dt]).requires_grad_()
+    x = torch.randn(2, 9, 9, 64, generator=g).to(DT[dt]).requires_grad_()
+    hair = (torch.rand(2, 9, 9, 1, generator=g) > 0.5).float()
+    back = (torch.rand(2, 9, 9, 1, generator=g) > 0.5).float()
+
+    def fn(bgf, x, hair, back):
+        y = ops.blend(bgf, x, hair, back)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).to(y.dtype).to(y.device)
+        return (y,) + torch.autograd.grad(y, (bgf, x), gy)
+    (hip, _), (ref, _) = _both(fn, (bgf, x, hair, back))
+    for a, r in zip(hip, ref):
+        _close(f"blend {dt}", a, r, TOL[dt])
+    if dt == "f32":
+        p = torch.randn(10007, generator=g)
+        gr = torch.randn(10007, generator=g)
+
+        def fa(p, gr):
+            p, m, v = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
+            for step in (1, 2, 3):
+                ops.adam_step(p, gr, m, v, lr=1e-3, beta1=0.0, beta2=0.9, eps=1e-8, step=step)
+            return p, m, v
+        (hip, _), (ref, _) = _both(fa, (p, gr))
+        for a, r in zip(hip, ref):
+            _close("adam", a, r, 1e-6)
+        # and against torch.optim.Adam itself
+        q = torch.nn.Parameter(p.clone().cuda())
+        opt = torch.optim.Adam([q], lr=1e-3, betas=(0.0, 0.9))
+        for _ in range(3):
+            q.grad = gr.cuda()
+            opt.step()
+        _close("adam vs torch.optim", hip[0], q.data, 1e-6)
+
+
+def test_conv_matches_miopen_large_bf16():
+    """Size-independent check at a BASELINE-sized layer (128->128 3x3 at 256^2, N=2): HIP conv vs
+    torch's own GPU conv (fp32), plus linearity conv(a*x) == a*conv(x)."""
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 256, 256, 128, generator=g).bfloat16().cuda()
+    w = (torch.randn(128, 128, 3, 3, generator=g) / 34).cuda()
+    y = ops.conv2d(x, w, None, padding=1).float()
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.bfloat16().float(), padding=1).permute(0, 2, 3, 1)
+    _close("conv vs torch gpu", y, ref, 2.0 ** -7)
+    y2 = ops.conv2d(x * 2, w, None, padding=1).float()
+    _close("linearity", y2, 2 * y, 2.0 ** -7)
