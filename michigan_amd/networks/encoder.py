@@ -1,0 +1,142 @@
+"""Appearance encoder (partial convolutions) and background encoder of the SPADEB generator
+(reference: models/networks/encoder.py:160-225,271-341, partialconv2d.py:15-86,
+MaskGAN_networks.py:114-173).  Activations are NHWC inside."""
+from __future__ import annotations
+
+import random
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .base_network import BaseNetwork
+from .layers import HipConv2d, HipInstanceNorm2d, reflect_pad_nhwc
+
+
+class PartialConv2d(HipConv2d):
+    """Single-channel-mask partial convolution that also returns the updated mask.
+
+    out = ((conv(x * m) - b) * ratio + b) * m',  ratio = k*k / (sum_window m + 1e-8) * m',
+    m' = clamp(sum_window m, 0, 1).  The conv runs on the MFMA kernel without bias, the
+    per-pixel renormalisation is a broadcast over channels."""
+
+    def __init__(self, *args, **kwargs):
+        kwargs.pop("multi_channel", None)
+        kwargs.pop("return_mask", None)
+        super().__init__(*args, **kwargs)
+
+    def forward(self, x, mask_in):                      # x NHWC, mask_in [N,H,W,1] float32
+        k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
+        with torch.no_grad():
+            m = mask_in.permute(0, 3, 1, 2)
+            upd = F.avg_pool2d(m, k, s, p, count_include_pad=True) * float(k * k)     # window sum
+            ratio = (k * k) / (upd + 1e-8)
+            upd = upd.clamp(0, 1)
+            ratio = (ratio * upd).permute(0, 2, 3, 1)
+            upd = upd.permute(0, 2, 3, 1).contiguous()
+        raw = ops.conv2d(x * mask_in.to(x.dtype), self.weight, None, stride=s, padding=p)
+        out = raw.float() * ratio
+        if self.bias is not None:
+            out = out + self.bias
+        return (out * upd).to(x.dtype), upd
+
+
+class ImageEncoder3(BaseNetwork):
+    """Five stride-2 partial convs + instance norm + LeakyReLU, then the mean feature of the
+    reference hair region broadcast over the target hair region and resized to the latent grid."""
+
+    def __init__(self, opt, sw, sh):
+        super().__init__()
+        ndf = opt.ngf
+        self.sw, self.sh, self.opt = sw, sh, opt
+        chans = [3, ndf, ndf * 2, ndf * 4, ndf * 8, ndf * 16]
+        for i in range(1, 6):
+            setattr(self, "layer%d" % i, PartialConv2d(chans[i - 1], chans[i], 3, stride=2, padding=1))
+            setattr(self, "norm%d" % i, HipInstanceNorm2d(chans[i]))
+        self.actvn = nn.LeakyReLU(0.2, False)
+
+    def forward(self, x, label_ref0, label_tag0):       # x NHWC; labels NCHW [N,1,H,W] float
+        use_norm = "instance" in self.opt.norm_ref_encode
+        mask = label_ref0.permute(0, 2, 3, 1).float().contiguous()
+        for i in range(1, 6):
+            x, mask = getattr(self, "layer%d" % i)(x, mask)
+            if use_norm:
+                x = getattr(self, "norm%d" % i)(x, act=ops.ACT_LRELU)     # norm_i then the next actvn, fused
+            else:
+                x = F.leaky_relu(x, 0.2)
+        n, xh, xw, c = x.shape
+        lref = F.interpolate(label_ref0.float(), size=(xh, xw), mode="nearest").permute(0, 2, 3, 1)
+        ltag = F.interpolate(label_tag0.float(), size=(xh, xw), mode="nearest").permute(0, 2, 3, 1)
+        xf = x.float()
+        area = lref.sum(dim=(1, 2, 3)).clamp_min(1.0)
+        mean_feat = (xf * lref).sum(dim=(1, 2)) / area[:, None]                    # [N, C]
+        out = mean_feat[:, None, None, :] * ltag                                     # [N, xh, xw, C]
+        if self.sh != xh:
+            out = F.interpolate(out.permute(0, 3, 1, 2), size=(self.sh, self.sw), mode="bilinear").permute(0, 2, 3, 1)
+        return out.to(x.dtype).contiguous()
+
+
+class ConvBlock(nn.Module):
+    """reflect pad -> conv (bias) -> ReLU, the only ConvBlock flavour on the hot path; the ReLU is
+    fused into the conv epilogue.  Key layout: `<name>.conv.{weight,bias}`."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, stride, padding=0, norm="none",
+                 activation="relu", pad_type="reflect"):
+        super().__init__()
+        if norm != "none" or activation != "relu" or pad_type != "reflect":
+            raise NotImplementedError("ConvBlock: only norm='none', activation='relu', pad_type='reflect'")
+        self.padding = padding
+        self.conv = HipConv2d(input_dim, output_dim, kernel_size, stride, bias=True)
+
+    def forward(self, x):                               # NHWC
+        return self.conv(reflect_pad_nhwc(x, self.padding), act=ops.ACT_RELU)
+
+
+class BackgroundEncode2(BaseNetwork):
+    """Background branch: grow the hair mask by a max-pool, paste noise into it, encode with a
+    7x7 and three 4x4/s2 reflect-padded convs; returns features and background masks, coarse to fine."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt, self.ngf = opt, opt.ngf
+        if opt.num_upsampling_layers == "most":
+            raise NotImplementedError("num_upsampling_layers='most' is outside the BASELINE configs")
+        ngf = opt.ngf
+        self.conv1 = ConvBlock(3, ngf, 7, 1, 3)
+        self.layer1 = ConvBlock(ngf, 2 * ngf, 4, 2, 1)
+        self.layer2 = ConvBlock(2 * ngf, 4 * ngf, 4, 2, 1)
+        self.layer3 = ConvBlock(4 * ngf, 8 * ngf, 4, 2, 1)
+        self.layer4 = ConvBlock(8 * ngf, 16 * ngf, 4, 2, 1)      # constructed but unused, as in the reference
+
+    def dilation_kernel(self, mask_h):
+        opt = self.opt
+        if opt.isTrain:
+            if not opt.random_expand_mask:
+                return None
+            th = int(mask_h * opt.random_expand_th)
+            th = th if th % 2 == 1 else th + 1
+            return random.choice([max(th - 4, 1), max(th - 2, 1), th, th + 2, th + 4])
+        return opt.expand_th if opt.expand_mask_be else None
+
+    def forward(self, image, mask, noise):              # all NCHW float (3 / 2 / 3 channels)
+        k = self.dilation_kernel(mask.shape[2])
+        if k is None:
+            back = mask[:, 0:1]
+        elif self.opt.add_feat_zeros and not self.opt.isTrain:
+            th, hh = self.opt.add_th, self.opt.crop_size
+            o = int(th / 2)
+            hair = mask[:, 1:2]
+            grown = hair * 0
+            grown[:, :, o:o + hh, o:o + hh] = F.max_pool2d(hair[:, :, o:o + hh, o:o + hh], k, 1, int(k / 2))
+            back = 1 - grown
+        else:
+            back = 1 - F.max_pool2d(mask[:, 1:2], kernel_size=k, stride=1, padding=int(k / 2))
+        inp = noise if self.opt.random_noise_background else image * back + noise * (1 - back)
+        x0 = self.conv1(ops.pad_channels(ops.to_nhwc(inp, self.compute_dtype), 8))
+        x1 = self.layer1(x0)
+        x2 = self.layer2(x1)
+        x3 = self.layer3(x2)
+        sh, sw = back.shape[2], back.shape[3]
+        masks = [F.interpolate(back, size=(int(sh / d), int(sw / d)), mode="nearest") for d in (8, 4, 2)] + [back]
+        return [x3, x2, x1, x0], masks

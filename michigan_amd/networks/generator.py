@@ -1,0 +1,93 @@
+"""SPADEB generator (reference: models/networks/generator.py:19-230)."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from .architecture import SPADEResnetBlock
+from .base_network import BaseNetwork
+from .encoder import BackgroundEncode2, ImageEncoder3
+from .layers import HipConv2d
+from .normalization import SegPyramid
+
+
+class SPADEBGenerator(BaseNetwork):
+    """Appearance code from the reference image -> 7 SPADE residual blocks with six nearest 2x
+    upsamplings, conditioned on [tag mask one-hot, orientation] -> background blend after up_0..up_3
+    -> 3x3 conv -> tanh.  forward() keeps the reference's keyword signature and NCHW tensors."""
+
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        parser.set_defaults(norm_G="spectralspadesyncbatch3x3")
+        return parser
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        nf = opt.ngf
+        self.sw, self.sh = self.compute_latent_vector_size(opt)
+        if opt.use_vae or not opt.use_encoder or opt.Image_encoder_mode != "partialconv":
+            raise NotImplementedError("HIP SPADEB generator: --use_encoder with Image_encoder_mode=partialconv only")
+        if not opt.noise_background:
+            raise NotImplementedError("HIP SPADEB generator: --noise_background (BackgroundEncode2) only")
+        self.fc = ImageEncoder3(opt, self.sw, self.sh)
+        self.head_0 = SPADEResnetBlock(16 * nf, 16 * nf, opt)
+        self.G_middle_0 = SPADEResnetBlock(16 * nf, 16 * nf, opt)
+        self.G_middle_1 = SPADEResnetBlock(16 * nf, 16 * nf, opt)
+        self.up_0 = SPADEResnetBlock(16 * nf, 8 * nf, opt)
+        self.up_1 = SPADEResnetBlock(8 * nf, 4 * nf, opt)
+        self.up_2 = SPADEResnetBlock(4 * nf, 2 * nf, opt)
+        self.up_3 = SPADEResnetBlock(2 * nf, 1 * nf, opt)
+        if opt.num_upsampling_layers == "most":
+            raise NotImplementedError("num_upsampling_layers='most' is outside the BASELINE configs")
+        self.conv_img = HipConv2d(nf, 3, 3, padding=1)
+        self.backgroud_enc = BackgroundEncode2(opt)
+
+    def compute_latent_vector_size(self, opt):
+        ups = {"normal": 5, "more": 6, "most": 7}
+        if opt.num_upsampling_layers not in ups:
+            raise ValueError("opt.num_upsampling_layers [%s] not recognized" % opt.num_upsampling_layers)
+        size = opt.crop_size + (opt.add_th if opt.add_feat_zeros else 0)
+        sw = size // (2 ** ups[opt.num_upsampling_layers])
+        return sw, round(sw / opt.aspect_ratio)
+
+    def forward(self, input=None, z=None, orient_mask=None, image_ref=None, input_tag=None, noise=None,
+                image_tag=None):
+        opt, dt = self.opt, self.compute_dtype
+        input_tag = input_tag.float()
+        hair = input_tag[:, 1:2]
+        x = self.fc(ops.pad_channels(ops.to_nhwc(image_ref, dt), 8), input[:, 1:2], hair)
+
+        seg = input_tag
+        if not opt.no_orientation:
+            if not opt.use_ig:
+                ang = orient_mask / 255.0 * math.pi
+                orient = torch.cat([torch.sin(2 * ang), torch.cos(2 * ang)], dim=1) * hair
+            else:
+                orient = orient_mask
+            if opt.orient_random_disturb:
+                raise NotImplementedError("--orient_random_disturb is outside the BASELINE configs")
+            seg = torch.cat([seg, orient.float()], dim=1)
+        pyramid = SegPyramid(seg, dt)
+
+        back_feats, back_masks = self.backgroud_enc(image_tag, input_tag, noise)
+        hh, hw = hair.shape[2], hair.shape[3]
+        hair_masks = [F.interpolate(hair, size=(int(hh / d), int(hw / d)), mode="nearest") for d in (8, 4, 2)] + [hair]
+
+        x = self.head_0(x, pyramid)
+        x = self.G_middle_0(ops.upsample2x(x), pyramid)
+        if opt.num_upsampling_layers == "more":
+            x = ops.upsample2x(x)
+        x = self.G_middle_1(x, pyramid)
+        for i, block in enumerate((self.up_0, self.up_1, self.up_2, self.up_3)):
+            x = block(ops.upsample2x(x), pyramid)
+            if opt.bf_direct_add:
+                x = back_feats[i] + x
+            else:
+                x = ops.blend(back_feats[i], x, hair_masks[i], back_masks[i])
+        # conv_img(leaky_relu(x)) then tanh: the LeakyReLU is an elementwise pass, tanh is the conv epilogue
+        x = self.conv_img(F.leaky_relu(x, 0.2), act=ops.ACT_TANH)
+        return ops.to_nchw(x)

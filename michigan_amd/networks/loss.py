@@ -1,0 +1,128 @@
+"""Losses that consume the hot path's outputs (reference: models/networks/loss.py:19-207).
+
+Reductions run in fp32 on whatever dtype the discriminator / VGG towers produced.  Only the
+loss classes on the BASELINE path are provided (hinge GAN loss with wide-edge weighting,
+discriminator feature matching, VGG perceptual loss); orientation / Lab / style losses are out of
+scope."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .architecture import VGG19
+
+
+class GANLoss(nn.Module):
+    def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0, tensor=torch.FloatTensor, opt=None):
+        super().__init__()
+        if gan_mode not in ("ls", "original", "w", "hinge"):
+            raise ValueError("Unexpected gan_mode {}".format(gan_mode))
+        self.gan_mode, self.opt = gan_mode, opt
+        self.real_label, self.fake_label = target_real_label, target_fake_label
+
+    def get_wide_edges(self, t, th=0.06):
+        h, w = t.shape[2], t.shape[3]
+        k = max(1, int(h * th))
+        p = int(k / 2)
+        grown = F.max_pool2d(t, kernel_size=k, stride=1, padding=p)
+        shrunk = 1 - F.max_pool2d(1 - t, kernel_size=k, stride=1, padding=p)
+        return F.interpolate(grown - shrunk, size=(h, w), mode="nearest")
+
+    def get_weight_mask(self, input, mask):
+        label = F.interpolate(mask, size=input.shape[2:], mode="nearest")
+        edges = self.get_wide_edges(label)
+        return edges * self.opt.wide_edge + (1 - edges)
+
+    def loss(self, input, target_is_real, for_discriminator=True, label=None):
+        input = input.float()
+        if self.gan_mode == "original":
+            target = torch.full_like(input, self.real_label if target_is_real else self.fake_label)
+            return F.binary_cross_entropy_with_logits(input, target)
+        if self.gan_mode == "ls":
+            target = torch.full_like(input, self.real_label if target_is_real else self.fake_label)
+            return F.mse_loss(input, target)
+        if self.gan_mode == "w":
+            return -input.mean() if target_is_real else input.mean()
+        if getattr(self.opt, "remove_background", False):
+            c = input.shape[1]
+            lab = F.interpolate(label, size=input.shape[2:], mode="nearest")
+            denom = lab.sum() * c + 1e-5
+            if not for_discriminator:
+                assert target_is_real, "The generator's hinge loss must be aiming for real"
+                return -(input * lab).sum() / denom
+            margin = ((input - 1) if target_is_real else (-input - 1)) * lab
+            return -torch.clamp_max(margin, 0).sum() / denom
+        if not for_discriminator:
+            assert target_is_real, "The generator's hinge loss must be aiming for real"
+            return -input.mean()
+        margin = torch.clamp_max((input - 1) if target_is_real else (-input - 1), 0)
+        if self.opt.wide_edge > 1.0:
+            margin = margin * self.get_weight_mask(input, label)
+        return -margin.mean()
+
+    def __call__(self, input, target_is_real, for_discriminator=True, label=None):
+        label = label.detach().float() if label is not None else None
+        if not isinstance(input, list):
+            return self.loss(input, target_is_real, for_discriminator, label)
+        total = 0
+        for pred in input:
+            pred = pred[-1] if isinstance(pred, list) else pred
+            val = self.loss(pred, target_is_real, for_discriminator, label)
+            bs = 1 if val.dim() == 0 else val.size(0)
+            total = total + val.view(bs, -1).mean(dim=1)
+        return total / len(input)
+
+
+class GANFeatLoss(nn.Module):
+    """L1 between the discriminator's intermediate features of fake and real, weight lambda_feat / num_D."""
+
+    def __init__(self, opt=None):
+        super().__init__()
+        self.opt = opt
+
+    def L1_loss_mask(self, input, target, label):
+        lab = F.interpolate(label, size=input.shape[2:], mode="nearest")
+        return (input * lab - target * lab).abs().sum() / (lab.sum() * input.shape[1] + 1e-5)
+
+    def forward(self, pred_fake, pred_real, label=None):
+        num_d = len(pred_fake)
+        total = pred_fake[0][0].new_zeros(1, dtype=torch.float32)
+        for i in range(num_d):
+            for j in range(len(pred_fake[i]) - 1):
+                a, b = pred_fake[i][j].float(), pred_real[i][j].detach().float()
+                if getattr(self.opt, "remove_background", False):
+                    val = self.L1_loss_mask(a, b, label.detach().float())
+                else:
+                    val = F.l1_loss(a, b)
+                total = total + val * self.opt.lambda_feat / num_d
+        return total
+
+
+class VGGLoss(nn.Module):
+    """Weighted L1 over the five VGG19 taps of x and (detached) y."""
+
+    def __init__(self, opt=None, vgg=None):
+        super().__init__()
+        self.vgg = vgg if vgg is not None else VGG19()
+        if torch.cuda.is_available():
+            self.vgg = self.vgg.cuda()
+        self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+        self.opt = opt
+
+    def L1_loss_mask(self, input, target, label):
+        lab = F.interpolate(label, size=input.shape[2:], mode="nearest")
+        return F.l1_loss(input * lab, target * lab, reduction="sum") / (lab.sum() * input.shape[1] + 1e-5)
+
+    def forward(self, x, y, label=None):
+        with torch.no_grad():
+            y_feats = self.vgg(y)
+        x_feats = self.vgg(x)
+        loss = 0
+        for w, a, b in zip(self.weights, x_feats, y_feats):
+            a, b = a.float(), b.detach().float()
+            if getattr(self.opt, "remove_background", False):
+                loss = loss + w * self.L1_loss_mask(a, b, label.detach().float())
+            else:
+                loss = loss + w * F.l1_loss(a, b)
+        return loss

@@ -1,0 +1,94 @@
+"""SPADE and the non-SPADE norm-layer factory (reference: models/networks/normalization.py:18-118)."""
+from __future__ import annotations
+
+import re
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils import spectral_norm
+
+from .. import ops
+from .layers import HipConv2d, HipInstanceNorm2d
+from .sync_batchnorm import SynchronizedBatchNorm2d
+
+
+class SegPyramid:
+    """The conditioning map (mask + orientation, NCHW float) and its nearest-neighbour resizes.
+
+    Every SPADE layer resizes the same map to its own resolution (normalization.py:109); the 18
+    layers of the generator need only 7 distinct sizes, so the resized NHWC/compute-dtype copies are
+    cached here (nearest source index = floor(dst * in / out), as F.interpolate does)."""
+
+    def __init__(self, seg_nchw: torch.Tensor, dtype):
+        self.seg, self.dtype, self._cache = seg_nchw, dtype, {}
+
+    def at(self, h: int, w: int) -> torch.Tensor:
+        key = (h, w)
+        if key not in self._cache:
+            s = self.seg if self.seg.shape[2:] == key else F.interpolate(self.seg, size=key, mode="nearest")
+            self._cache[key] = ops.pad_channels(ops.to_nhwc(s, self.dtype), 8)
+        return self._cache[key]
+
+
+class SPADE(nn.Module):
+    """Spatially-adaptive normalisation, one fused launch per layer.
+
+    Parameters / buffers (and therefore state_dict keys) are the reference's: param_free_norm
+    (running stats), mlp_shared.0, mlp_gamma, mlp_beta.  forward(x, segmap) takes NHWC activations
+    and either a SegPyramid or an NCHW map; `act` fuses the LeakyReLU that always follows in the
+    residual block (architecture.py:70-71) and `stats` lets norm_0 / norm_s share one reduction of
+    the same x."""
+
+    def __init__(self, config_text, norm_nc, label_nc, use_weight_norm=False):
+        super().__init__()
+        if not config_text.startswith("spade"):
+            raise ValueError("SPADE config must start with 'spade', got %s" % config_text)
+        m = re.search(r"spade(\D+)(\d)x\d", config_text)
+        kind, ks = str(m.group(1)), int(m.group(2))
+        if kind not in ("syncbatch", "batch"):
+            raise ValueError("%s is not a recognized param-free norm type in SPADE" % kind)
+        if use_weight_norm:
+            raise NotImplementedError("weight-norm SPADE variant is outside the HIP hot path")
+        self.param_free_norm = SynchronizedBatchNorm2d(norm_nc, affine=False)
+        nhidden, pw = 128, ks // 2
+        self.mlp_shared = nn.Sequential(HipConv2d(label_nc, nhidden, kernel_size=ks, padding=pw), nn.ReLU())
+        self.mlp_gamma = HipConv2d(nhidden, norm_nc, kernel_size=ks, padding=pw)
+        self.mlp_beta = HipConv2d(nhidden, norm_nc, kernel_size=ks, padding=pw)
+        self.use_weight_norm = use_weight_norm
+
+    def forward(self, x, segmap, act=ops.ACT_NONE, stats=None):
+        n, h, w, c = x.shape
+        seg = segmap.at(h, w) if isinstance(segmap, SegPyramid) else SegPyramid(segmap, x.dtype).at(h, w)
+        mean, rstd, count = self.param_free_norm.statistics(x, stats)
+        actv = self.mlp_shared[0](seg, act=ops.ACT_RELU)
+        return ops.spade_modulate(x, actv, self.mlp_gamma.weight, self.mlp_gamma.bias,
+                                  self.mlp_beta.weight, self.mlp_beta.bias, mean, rstd, count,
+                                  act=act, slope=0.2)
+
+
+class _ConvNorm(nn.Sequential):
+    """conv -> instance norm with the following LeakyReLU fused into the norm kernel."""
+
+    def forward(self, x, act=ops.ACT_NONE, slope=0.2):
+        return self[1](self[0](x), act=act, slope=slope)
+
+
+def get_nonspade_norm_layer(opt, norm_type="instance"):
+    """Returns add_norm_layer(conv): optional spectral norm on the conv, then 'instance' / 'none'
+    normalisation; the conv's bias is dropped when a norm follows (normalization.py:18-54)."""
+    def add_norm_layer(layer):
+        sub = norm_type
+        if norm_type.startswith("spectral"):
+            layer = spectral_norm(layer)
+            sub = norm_type[len("spectral"):]
+        if sub == "none" or len(sub) == 0:
+            return layer
+        if getattr(layer, "bias", None) is not None:
+            delattr(layer, "bias")
+            layer.register_parameter("bias", None)
+        cout = getattr(layer, "out_channels", None) or layer.weight.size(0)
+        if sub == "instance":
+            return _ConvNorm(layer, HipInstanceNorm2d(cout))
+        raise ValueError("normalization layer %s is not recognized" % sub)
+    return add_norm_layer

@@ -1,0 +1,78 @@
+"""Synchronized batch norm state + the data-parallel wrapper the trainer imports
+(reference: models/networks/sync_batchnorm/{batchnorm,comm,replicate}.py).
+
+MI355X-first redesign: one process per GPU; statistics are reduced on the GPU by the HIP
+channel-stats kernel and exchanged with ONE RCCL all-reduce of a packed [2C+1] vector per layer
+(michigan_amd.ops.batch_stats) instead of the reference's master/slave Python-thread pipe with
+ReduceAddCoalesced + Broadcast (batchnorm.py:105-126, comm.py:18-137).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class SynchronizedBatchNorm2d(nn.Module):
+    """Holds running_mean / running_var / num_batches_tracked (and affine weight/bias when asked)
+    under the reference's state_dict keys and produces the statistics the fused kernels consume.
+
+    statistics(x) -> (mean, rstd, count): batch statistics in training (biased variance + eps
+    under the square root, exactly F.batch_norm on one device, batchnorm.py:65-68; summed over all
+    ranks of the sync group otherwise), running statistics in eval.  Running buffers are updated
+    with the unbiased variance and momentum 0.1; num_batches_tracked is never incremented (the
+    reference overrides forward and calls F.batch_norm directly).
+    """
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True):
+        super().__init__()
+        self.num_features, self.eps, self.momentum, self.affine = num_features, eps, momentum, affine
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def statistics(self, x, precomputed=None):
+        if not self.training:
+            rstd = torch.rsqrt(self.running_var.float() + self.eps)
+            return self.running_mean.float().contiguous(), rstd.contiguous(), math.inf
+        mean, rstd, unbiased, count = precomputed if precomputed is not None else ops.batch_stats(x, self.eps)
+        with torch.no_grad():
+            self.running_mean.mul_(1 - self.momentum).add_(mean, alpha=self.momentum)
+            self.running_var.mul_(1 - self.momentum).add_(unbiased, alpha=self.momentum)
+        return mean, rstd, count
+
+    def forward(self, x):                                          # NHWC, stand-alone use
+        mean, rstd, _ = self.statistics(x)
+        y = (x.float() - mean) * rstd
+        if self.affine:
+            y = y * self.weight + self.bias
+        return y.to(x.dtype)
+
+    def extra_repr(self):
+        return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}, affine={self.affine}"
+
+
+class DataParallelWithCallback(nn.Module):
+    """Drop-in for the name the trainer imports (pix2pix_trainer.py:6,21-24): exposes `.module`
+    and forwards calls.  Data parallelism itself is process-per-GPU (michigan_amd.parallel):
+    this wrapper registers the module with the gradient all-reducer when a process group exists,
+    so `DataParallelWithCallback(model, device_ids=opt.gpu_ids)` keeps working unchanged."""
+
+    def __init__(self, module, device_ids=None):
+        super().__init__()
+        self.module = module
+        self.device_ids = list(device_ids) if device_ids is not None else []
+        from .. import parallel
+        self.reducer = parallel.attach(module)
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)

@@ -1,0 +1,126 @@
+"""TEST INFRASTRUCTURE ONLY -- import the *unmodified* reference (/root/reference) in
+this container so that its own modules can (a) pin oracle/michigan_oracle.py and
+(b) generate the golden fixtures under tests/golden/ (oracle/make_golden.py).
+
+The reference does not import as shipped here: torchvision,
+cv2 and dominate are missing and a few call sites hard-code ``.cuda()``.  This
+harness supplies stub modules and shims from the OUTSIDE; nothing under
+/root/reference is touched or copied.  /root/reference does not exist on the GPU
+box, so nothing that runs there may import this file.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+
+REFERENCE_ROOT = os.environ.get("MICHIGAN_REFERENCE", "/root/reference")
+
+VGG19_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "models", "networks"))
+
+
+def _vgg19_stub(pretrained=False, **_):
+    """torchvision.models.vgg19 architecture (configuration E); weights are whatever the
+    caller loads -- the pretrained ImageNet weights are not available offline."""
+    layers, c = [], 3
+    for v in VGG19_CFG:
+        if v == "M":
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(c, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            c = v
+    m = nn.Module()
+    m.features = nn.Sequential(*layers)
+    return m
+
+
+def _install_stubs():
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tvm = types.ModuleType("torchvision.models")
+        tvm.vgg19 = _vgg19_stub
+        tvt = types.ModuleType("torchvision.transforms")
+        for name in ("Compose", "Lambda", "Resize", "ToTensor", "Normalize", "ColorJitter"):
+            setattr(tvt, name, type(name, (), {"__init__": lambda self, *a, **k: None}))
+        tv.models, tv.transforms = tvm, tvt
+        sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.transforms": tvt})
+    if "cv2" not in sys.modules:
+        sys.modules["cv2"] = types.ModuleType("cv2")
+    if "dominate" not in sys.modules:
+        dm = types.ModuleType("dominate")
+        dmt = types.ModuleType("dominate.tags")
+        dm.tags = dmt
+        sys.modules.update({"dominate": dm, "dominate.tags": dmt})
+
+
+_ready = False
+
+
+def setup():
+    """Make ``import models.networks`` resolve to the reference.  Idempotent."""
+    global _ready
+    if _ready:
+        return
+    if not reference_available():
+        raise RuntimeError(f"reference not found at {REFERENCE_ROOT}")
+    _install_stubs()
+    if not torch.cuda.is_available():
+        # loss.py hard-codes .cuda() / torch.cuda.FloatTensor; on a CPU-only host make them no-ops
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        nn.Module.cuda = lambda self, *a, **k: self
+        torch.cuda.FloatTensor = torch.FloatTensor
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    _ready = True
+
+
+def make_opt(**over) -> argparse.Namespace:
+    """The option namespace the reference's G / D constructors read (defaults =
+    options/base_options.py + the README training flags)."""
+    d = dict(
+        ngf=64, ndf=64, crop_size=512, aspect_ratio=1.0, label_nc=2, orient_nc=2, output_nc=3,
+        netG="spadeb", netD="multiscale", norm_G="spectralspadesyncbatch3x3", norm_D="spectralinstance",
+        norm_E="spectralinstance", num_upsampling_layers="more", use_vae=False, use_encoder=True,
+        Image_encoder_mode="partialconv", norm_ref_encode="instance", add_feat_zeros=False, add_th=64,
+        noise_background=True, weight_norm_G=False, weight_norm_g=0, no_orientation=False,
+        use_instance_feat=False, feat_num=3, use_ig=True, orient_random_disturb=False, isTrain=True,
+        expand_mask_be=True, expand_th=5, random_noise_background=False, use_clip=False, clip_th=300,
+        bf_direct_add=False, random_expand_mask=False, random_expand_th=0.05, z_dim=256, gpu_ids=[],
+        num_D=2, netD_subarch="n_layer", n_layers_D=4, contain_dontcare_label=False, no_instance=True,
+        no_ganFeat_loss=False, init_type="xavier", init_variance=0.02, remove_background=False,
+        wide_edge=2.0, gan_mode="hinge", lambda_feat=10.0, lambda_vgg=10.0,
+    )
+    d.update(over)
+    return argparse.Namespace(**d)
+
+
+def build_generator(opt):
+    setup()
+    from models.networks.generator import SPADEBGenerator
+    return SPADEBGenerator(opt)
+
+
+def build_discriminator(opt):
+    setup()
+    from models.networks.discriminator import MultiscaleDiscriminator
+    return MultiscaleDiscriminator(opt)
+
+
+def build_vgg():
+    setup()
+    from models.networks.architecture import VGG19
+    return VGG19()
+
+
+def losses():
+    setup()
+    import models.networks.loss as L
+    return L
