@@ -1,0 +1,163 @@
+"""MichiGAN hot-path benchmark: training images/s at 512x512 (G step + D step) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" = Pix2PixTrainer.run_generator_one_step + run_discriminator_one_step on one synthetic
+batch already resident in HBM (BASELINE.json configs[2]: full G+D+VGG train step, bs=8 per GPU,
+512x512, bf16 activations with fp32 accumulation / BN statistics / master weights).  Weak scaling:
+the per-GPU batch is fixed, data parallel over ranks with RCCL (sync-BN statistics + bucketed
+gradient all-reduce overlapped with backward).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work per 512^2 image (SURVEY.md section 8d / BASELINE.md section 3), GFLOP
+F_G, F_D, F_V = 1114.2, 70.9, 189.3
+STEP_GFLOP_REFERENCE = 4 * F_G + 6 * F_D + 6 * F_V          # 6018: what the reference executes
+STEP_GFLOP_MINIMUM = 4 * F_G + 4.5 * F_D + 3 * F_V          # 5344: without its discarded work
+PEAK_BF16_TFLOPS, PEAK_F32_TFLOPS = 2500.0, 157.3           # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=8)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+class ConvMeter:
+    """HIP-event timing of every mg_conv_taps launch of one extra (untimed) training step, on the
+    stream the kernels are launched on; algorithmic FLOPs from the launch geometry."""
+
+    def __init__(self):
+        from michigan_amd import ops
+        self.ops, self.records, self._orig = ops, [], ops._launch_conv
+
+    def __enter__(self):
+        orig, recs = self._orig, self.records
+
+        def timed(inp, wt, out, bias, taps, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            orig(inp, wt, out, bias, taps, **kw)
+            e.record()
+            flops = 2.0 * inp.shape[0] * kw["Hj"] * kw["Wj"] * kw["cout_gemm"] * kw.get("algo_cin", inp.shape[3]) * len(taps)
+            recs.append((s, e, flops, inp.dtype))
+        self.ops._launch_conv = timed
+        return self
+
+    def __exit__(self, *a):
+        self.ops._launch_conv = self._orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(s.elapsed_time(e) for s, e, _, _ in self.records)
+        fl = sum(f for _, _, f, _ in self.records)
+        return len(self.records), ms, fl
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from michigan_amd import _cabi
+    from michigan_amd.model import Pix2PixTrainer, default_options
+    from michigan_amd.synth import synth_batch
+    assert _cabi.backend().name == "hip"
+
+    torch.manual_seed(0)
+    opt = default_options(crop_size=a.size, gpu_ids=[local], compute_dtype=a.dtype)
+    trainer = Pix2PixTrainer(opt)
+    data = {k: v.cuda() for k, v in synth_batch(a.batch_per_gpu, a.size, seed=1234 + rank).items()}
+
+    def step():
+        trainer.run_generator_one_step(data)
+        trainer.run_discriminator_one_step(data)
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = {k: float(v.float().mean()) for k, v in trainer.get_latest_losses().items()}
+
+    roof = None
+    if rank == 0 and not a.no_roofline:
+        with ConvMeter() as m:
+            step()
+        n, ms, fl = m.summary()
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_taps_kernel (fwd + dgrad launches of one train step)",
+                "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "launches": n, "kernel_ms_per_step": round(ms, 3), "algorithmic_gflop_per_step": round(fl / 1e9, 1)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        gbatch = a.batch_per_gpu * world
+        ms_step = dt / a.steps * 1e3
+        value = gbatch * a.steps / dt
+        out = {
+            "metric": "training images/sec at 512x512 (G+D step)", "value": round(value, 3), "unit": "images/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if a.dtype == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"SPADEB G + multiscale PatchGAN D + VGG19 loss, full G step + D step (Adam), "
+                                   f"bs={a.batch_per_gpu}/GPU, {a.size}x{a.size}, BASELINE.json configs[2]",
+                       "global_batch": gbatch, "batch_per_gpu": a.batch_per_gpu, "resolution": a.size,
+                       "parallelism": f"dp{world}", "init": "reference default (xavier, 0.02), random VGG weights"},
+            "step_tflops_effective": {"vs_reference_work_6018GF": round(value * STEP_GFLOP_REFERENCE / 1e3 / world, 1),
+                                      "vs_minimum_work_5344GF": round(value * STEP_GFLOP_MINIMUM / 1e3 / world, 1),
+                                      "unit": "TFLOP/s per GPU"},
+            "losses": losses,
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle.cpu_baseline import time_train_step
+            secs, n_img, threads = time_train_step(size=a.size, n=1)
+            out["cpu_baseline"] = {"value": round(n_img / secs, 4), "unit": "images/s", "cores": threads, "kind": "port",
+                                   "sample": f"oracle (torch-CPU restatement of the reference) G step + D step, fwd+bwd, "
+                                             f"bs=1 at {a.size}x{a.size}, fp32, 1 iteration, {secs:.1f} s"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,200 @@
+"""The G+D training step of the hot path, behind the reference's model / trainer interface.
+
+`Pix2PixModel.forward(data, mode)` and `Pix2PixTrainer.run_generator_one_step /
+run_discriminator_one_step` keep the reference's names and call structure
+(models/pix2pix_model.py:62-93,257-398, trainers/pix2pix_trainer.py:39-77) for the losses that
+sit on the hot path under the README flags:  hinge GAN (wide_edge), discriminator feature
+matching and VGG perceptual loss.  The orientation / Lab / style / background losses and the
+frozen in-painting net are outside this tier's scope and raise if enabled.
+
+Differences that do not change results (SURVEY.md section 8a "parity-preserving minimum"):
+  * the discriminator's parameters do not require grad during the generator step (their
+    gradients are zeroed before use in the reference, pix2pix_trainer.py:64);
+  * the StyleContent VGG passes whose outputs the README flags discard are not executed.
+"""
+from __future__ import annotations
+
+import argparse
+import math
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from . import networks, parallel
+from .optim import FlatAdam
+
+
+def default_options(**over) -> argparse.Namespace:
+    """Option namespace = options/base_options.py + train_options.py defaults + the README training flags."""
+    d = dict(
+        ngf=64, ndf=64, crop_size=512, aspect_ratio=1.0, label_nc=2, orient_nc=2, output_nc=3,
+        netG="spadeb", netD="multiscale", norm_G="spectralspadesyncbatch3x3", norm_D="spectralinstance",
+        num_upsampling_layers="more", use_vae=False, use_encoder=True, Image_encoder_mode="partialconv",
+        norm_ref_encode="instance", add_feat_zeros=False, add_th=64, noise_background=True, weight_norm_G=False,
+        no_orientation=False, use_instance_feat=False, feat_num=3, use_ig=True, orient_random_disturb=False,
+        isTrain=True, expand_mask_be=True, expand_th=5, random_noise_background=False, bf_direct_add=False,
+        random_expand_mask=True, random_expand_th=0.05, gpu_ids=[0], num_D=2, netD_subarch="n_layer",
+        n_layers_D=4, contain_dontcare_label=False, no_instance=True, no_ganFeat_loss=False, no_vgg_loss=False,
+        no_gan_loss=False, init_type="xavier", init_variance=0.02, remove_background=False, wide_edge=2.0,
+        gan_mode="hinge", lambda_feat=1.0, lambda_vgg=1.0, lr=0.0002, beta1=0.5, beta2=0.999, no_TTUR=False,
+        compute_dtype="bf16", curr_step=1, niter=50, niter_decay=0,
+    )
+    d.update(over)
+    return argparse.Namespace(**d)
+
+
+class Pix2PixModel(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.netG = networks.define_G(opt)
+        self.netD = networks.define_D(opt) if opt.isTrain else None
+        if opt.isTrain:
+            self.criterionGAN = networks.GANLoss(opt.gan_mode, opt=opt)
+            self.criterionGANFeat = networks.GANFeatLoss(opt)
+            if not opt.no_vgg_loss:
+                self.criterionVGG = networks.VGGLoss(opt)
+                dt = getattr(opt, "compute_dtype", None)
+                if dt is not None:
+                    self.criterionVGG.vgg.compute_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}.get(dt, dt)
+
+    # -- data ---------------------------------------------------------------------
+    def preprocess_input(self, data: Dict[str, torch.Tensor]):
+        """Accepts either the reference's loader dict (label_tag/label_ref index maps, pix2pix_model.py:209-254)
+        or already one-hot maps (michigan_amd.synth.synth_batch)."""
+        dev = next(self.netG.parameters()).device
+        out = {}
+        for k in ("input_tag", "input_ref", "image_tag", "image_ref", "orient", "noise"):
+            if k in data:
+                out[k] = data[k].to(dev, non_blocking=True)
+        for src, dst in (("label_tag", "input_tag"), ("label_ref", "input_ref")):
+            if dst not in out:
+                lab = data[src].long().to(dev)
+                nc = self.opt.label_nc + (1 if self.opt.contain_dontcare_label else 0)
+                out[dst] = torch.zeros(lab.shape[0], nc, lab.shape[2], lab.shape[3], device=dev).scatter_(1, lab, 1.0)
+        return out
+
+    def orientation_planes(self, d):
+        o = d["orient"]
+        if o.shape[1] == 1 and not self.opt.use_ig:
+            ang = o / 255.0 * math.pi
+            return torch.cat([torch.sin(2 * ang), torch.cos(2 * ang)], dim=1) * d["input_tag"][:, 1:2]
+        return o
+
+    # -- networks -------------------------------------------------------------------
+    def generate_fake(self, d):
+        return self.netG(d["input_ref"], orient_mask=d["orient"], image_ref=d["image_ref"],
+                         input_tag=d["input_tag"], noise=d["noise"], image_tag=d["image_tag"])
+
+    def discriminate(self, d, fake_image):
+        orient = self.orientation_planes(d).to(fake_image.dtype)
+        tag = d["input_tag"].to(fake_image.dtype)
+        fake = torch.cat([tag, orient, fake_image], dim=1)
+        real = torch.cat([tag, orient, d["image_tag"].to(fake_image.dtype)], dim=1)
+        out = self.netD(torch.cat([fake, real], dim=0))
+        half = lambda t: t.size(0) // 2
+        pred_fake = [[t[:half(t)] for t in p] for p in out]
+        pred_real = [[t[half(t):] for t in p] for p in out]
+        return pred_fake, pred_real
+
+    def compute_generator_loss(self, d):
+        losses = {}
+        fake = self.generate_fake(d)
+        pred_fake, pred_real = self.discriminate(d, fake)
+        label = d["input_tag"][:, 1:2]
+        if not self.opt.no_gan_loss:
+            losses["GAN"] = self.criterionGAN(pred_fake, True, for_discriminator=False, label=label)
+        ref_is_tag = bool((d["input_tag"][:, 1] - d["input_ref"][:, 1]).sum() == 0)
+        if self.opt.curr_step == 1 and ref_is_tag:
+            if not self.opt.no_ganFeat_loss:
+                losses["GAN_Feat"] = self.criterionGANFeat(pred_fake, pred_real, label)
+            if not self.opt.no_vgg_loss:
+                losses["VGG"] = self.criterionVGG(fake, d["image_tag"], label) * self.opt.lambda_vgg
+        return losses, fake
+
+    def compute_discriminator_loss(self, d):
+        with torch.no_grad():
+            fake = self.generate_fake(d)
+        fake = fake.detach()
+        pred_fake, pred_real = self.discriminate(d, fake)
+        label = d["input_tag"][:, 1:2]
+        return {"D_Fake": self.criterionGAN(pred_fake, False, for_discriminator=True, label=label),
+                "D_real": self.criterionGAN(pred_real, True, for_discriminator=True, label=label)}
+
+    def forward(self, data, mode):
+        d = self.preprocess_input(data)
+        if mode == "generator":
+            return self.compute_generator_loss(d)
+        if mode == "discriminator":
+            return self.compute_discriminator_loss(d)
+        if mode == "inference":
+            with torch.no_grad():
+                return self.generate_fake(d)
+        raise ValueError("|mode| is invalid")
+
+    def create_optimizers(self, opt, group=None):
+        if opt.no_TTUR:
+            betas, g_lr, d_lr = (opt.beta1, opt.beta2), opt.lr, opt.lr
+        else:
+            betas, g_lr, d_lr = (0.0, 0.9), opt.lr / 2, opt.lr * 2
+        return (FlatAdam(self.netG.parameters(), lr=g_lr, betas=betas, group=group),
+                FlatAdam(self.netD.parameters(), lr=d_lr, betas=betas, group=group))
+
+
+class Pix2PixTrainer:
+    """G/D alternation with resident weights; one instance per process (= per GPU)."""
+
+    def __init__(self, opt):
+        self.opt = opt
+        self.pix2pix_model = Pix2PixModel(opt)
+        if len(opt.gpu_ids) > 0 and torch.cuda.is_available():
+            self.pix2pix_model.cuda()
+        self.pix2pix_model_on_one_gpu = self.pix2pix_model
+        group = parallel.init()
+        if group is not None:
+            parallel.broadcast_parameters(self.pix2pix_model.netG)
+            parallel.broadcast_parameters(self.pix2pix_model.netD)
+        self.optimizer_G, self.optimizer_D = self.pix2pix_model.create_optimizers(opt, group)
+        self.old_lr = opt.lr
+        self.g_losses, self.d_losses, self.generated = {}, {}, None
+
+    def _set_d_requires_grad(self, flag: bool):
+        for p in self.optimizer_D.params:
+            p.requires_grad_(flag)
+
+    def run_generator_one_step(self, data):
+        self.optimizer_G.zero_grad()
+        self._set_d_requires_grad(False)
+        try:
+            g_losses, generated = self.pix2pix_model(data, mode="generator")
+            g_loss = sum(g_losses.values()).mean()
+            g_loss.backward()
+        finally:
+            self._set_d_requires_grad(True)
+        self.optimizer_G.step()
+        self.g_losses, self.generated = g_losses, generated
+
+    def run_discriminator_one_step(self, data):
+        self.optimizer_D.zero_grad()
+        d_losses = self.pix2pix_model(data, mode="discriminator")
+        d_loss = sum(d_losses.values()).mean()
+        d_loss.backward()
+        self.optimizer_D.step()
+        self.d_losses = d_losses
+
+    def get_latest_losses(self):
+        return {**self.g_losses, **self.d_losses}
+
+    def get_latest_generated(self):
+        return self.generated
+
+    def update_learning_rate(self, epoch):
+        new_lr = self.old_lr - self.opt.lr / self.opt.niter_decay if epoch > self.opt.niter else self.old_lr
+        if new_lr != self.old_lr:
+            g, d = (new_lr, new_lr) if self.opt.no_TTUR else (new_lr / 2, new_lr * 2)
+            for grp in self.optimizer_G.param_groups:
+                grp["lr"] = g
+            for grp in self.optimizer_D.param_groups:
+                grp["lr"] = d
+            self.old_lr = new_lr

@@ -97,7 +97,7 @@ def pad_channels(x: torch.Tensor, mult: int = 8) -> torch.Tensor:
 # ----------------------------------------------------------------------------
 def _launch_conv(inp, wt, out, bias, taps, *, Hj, Wj, isy, isx, osy=1, osx=1, ooy=0, oox=0,
                  cout, cout_gemm, act=ACT_NONE, slope=0.2, resid=None,
-                 spade_x=None, mean=None, rstd=None, gamma_out=None):
+                 spade_x=None, mean=None, rstd=None, gamma_out=None, algo_cin=None):
     d = C.ConvDesc()
     d.in_, d.wt, d.out = inp.data_ptr(), wt.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None

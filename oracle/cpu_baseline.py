@@ -1,0 +1,58 @@
+"""TEST/BENCH INFRASTRUCTURE ONLY -- time the oracle (torch-CPU restatement of the reference's
+G+D+VGG training step) on the host cores.  Used by bench.py's `cpu_baseline` leg (kind "port":
+/root/reference itself cannot travel to the GPU box) and nowhere in the product."""
+from __future__ import annotations
+
+import os
+import random
+import time
+
+import torch
+
+from michigan_amd.model import default_options
+from michigan_amd.synth import synth_batch, synth_state_dict
+from oracle import michigan_oracle as O
+
+
+def _leafify(sd):
+    out = {}
+    for k, v in sd.items():
+        train = v.is_floating_point() and "running" not in k and not k.endswith("weight_u") and not k.endswith("weight_v")
+        out[k] = v.clone().requires_grad_(train)
+    return out
+
+
+def time_train_step(size: int = 512, n: int = 1, threads: int | None = None):
+    """One generator step (GAN + feature matching + VGG losses, backward) and one discriminator step
+    (generator forward under no_grad, D forward/backward) of the oracle; returns (seconds, images, threads)."""
+    from michigan_amd import networks
+    threads = threads or os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    opt = default_options(crop_size=size, gpu_ids=[])
+    with torch.device("meta"):
+        shapes = {"G": networks.SPADEBGenerator(opt).state_dict(), "D": networks.MultiscaleDiscriminator(opt).state_dict(),
+                  "V": networks.VGG19().state_dict()}
+    tmpl = {k: {kk: torch.empty(vv.shape, dtype=vv.dtype) for kk, vv in v.items()} for k, v in shapes.items()}
+    sdg = _leafify(synth_state_dict(tmpl["G"], seed=1))
+    sdd = _leafify(synth_state_dict(tmpl["D"], seed=2))
+    sdv = synth_state_dict(tmpl["V"], seed=3, gain=1.4)
+    b = synth_batch(n, size, seed=1234)
+    random.seed(0)
+    t0 = time.perf_counter()
+    # generator step
+    fake = O.spadeb_generator(sdg, opt, b["input_ref"], b["orient"], b["image_ref"], b["input_tag"], b["noise"], b["image_tag"], True, {})
+    sdd_const = {k: v.detach() for k, v in sdd.items()}
+    pf, pr = O.discriminate(sdd_const, b["input_tag"], b["orient"], fake, b["image_tag"], True, {})
+    label = b["input_tag"][:, 1:2]
+    loss = O.gan_hinge_loss(pf, True, False, label, opt.wide_edge) + O.gan_feat_loss(pf, pr, opt.lambda_feat)
+    with torch.no_grad():
+        yf = O.vgg19_features(b["image_tag"], sdv)
+    loss = loss + O.vgg_loss(O.vgg19_features(fake, sdv), yf) * opt.lambda_vgg
+    loss.sum().backward()
+    # discriminator step
+    with torch.no_grad():
+        fake2 = O.spadeb_generator(sdg, opt, b["input_ref"], b["orient"], b["image_ref"], b["input_tag"], b["noise"], b["image_tag"], True, {})
+    pf, pr = O.discriminate(sdd, b["input_tag"], b["orient"], fake2, b["image_tag"], True, {})
+    dl = O.gan_hinge_loss(pf, False, True, label, opt.wide_edge) + O.gan_hinge_loss(pr, True, True, label, opt.wide_edge)
+    dl.sum().backward()
+    return time.perf_counter() - t0, n, threads

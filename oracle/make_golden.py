@@ -1,0 +1,136 @@
+"""Generate tests/golden/*.npz by running the REFERENCE ITSELF (unmodified, imported from
+/root/reference through oracle/ref_harness.py) on seeded synthetic inputs and weights.
+
+Run in the build container only (the reference is not on the GPU box):
+    python oracle/make_golden.py
+Inputs/weights are not stored: michigan_amd.synth regenerates them bit-identically from the seeds
+recorded in each file, so the fixtures stay small.  What is stored are the reference's outputs:
+generator image, per-block feature statistics, updated BN / spectral-norm buffers, parameter
+gradient norms (+ a few full gradients), discriminator and VGG outputs, and the loss values of
+one generator and one discriminator step.
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from michigan_amd.synth import synth_batch, synth_state_dict  # noqa: E402
+from oracle import ref_harness as R  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+CFG = dict(ngf=16, ndf=16, crop_size=128, n=2, seed_w=1, seed_d=2, seed_v=3, seed_x=5, seed_py=3, gain=1.0,
+           random_expand_mask=True, wide_edge=2.0, lambda_feat=1.0, lambda_vgg=1.0)
+
+
+def stats(t):
+    t = t.detach().double()
+    return np.array([t.mean().item(), t.abs().mean().item(), t.std().item(), t.abs().max().item()])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    opt = R.make_opt(ngf=CFG["ngf"], ndf=CFG["ndf"], crop_size=CFG["crop_size"], random_expand_mask=True,
+                     wide_edge=CFG["wide_edge"], lambda_feat=CFG["lambda_feat"], lambda_vgg=CFG["lambda_vgg"])
+    b = synth_batch(CFG["n"], CFG["crop_size"], seed=CFG["seed_x"])
+
+    # ---- generator forward + backward --------------------------------------------------------
+    G = R.build_generator(opt).train()
+    G.load_state_dict(synth_state_dict(G.state_dict(), seed=CFG["seed_w"], gain=CFG["gain"]))
+    taps = {}
+    hooks = [getattr(G, name).register_forward_hook(lambda m, i, o, name=name: taps.__setitem__(name, o))
+             for name in ("head_0", "G_middle_0", "G_middle_1", "up_0", "up_1", "up_2", "up_3")]
+    random.seed(CFG["seed_py"])
+    out = G(b["input_ref"], orient_mask=b["orient"], image_ref=b["image_ref"], input_tag=b["input_tag"],
+            noise=b["noise"], image_tag=b["image_tag"])
+    for h in hooks:
+        h.remove()
+    gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(99))
+    (out * gy).sum().backward()
+    sd_after = G.state_dict()
+    g = {"out": out.detach().numpy()}
+    for k, v in taps.items():
+        g["tapstat." + k] = stats(v)
+    for k in ("up_3.norm_0.param_free_norm.running_mean", "up_3.norm_0.param_free_norm.running_var",
+              "head_0.norm_1.param_free_norm.running_mean", "head_0.norm_1.param_free_norm.running_var",
+              "up_0.norm_s.param_free_norm.running_var", "up_3.conv_0.weight_u", "head_0.conv_1.weight_v",
+              "up_0.conv_s.weight_u"):
+        g["buf." + k] = sd_after[k].numpy()
+    names, norms = [], []
+    for k, p in G.named_parameters():
+        names.append(k)
+        norms.append(-1.0 if p.grad is None else p.grad.double().norm().item())
+    g["grad_norms"] = np.array(norms)
+    for k in ("conv_img.weight", "up_3.norm_1.mlp_gamma.bias", "up_3.conv_0.weight_orig", "fc.layer1.weight",
+              "backgroud_enc.layer3.conv.bias", "head_0.norm_0.mlp_shared.0.weight"):
+        g["grad." + k] = dict(G.named_parameters())[k].grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "generator_ngf16_c128.npz"), **g)
+    with open(os.path.join(OUT, "generator_param_names.json"), "w") as fh:
+        json.dump(names, fh)
+
+    # ---- discriminator + losses + VGG --------------------------------------------------------
+    D = R.build_discriminator(opt).train()
+    D.load_state_dict(synth_state_dict(D.state_dict(), seed=CFG["seed_d"], gain=CFG["gain"]))
+    V = R.build_vgg()
+    V.load_state_dict(synth_state_dict(V.state_dict(), seed=CFG["seed_v"], gain=1.4))
+    L = R.losses()
+    gan = L.GANLoss("hinge", tensor=torch.FloatTensor, opt=opt)
+    feat = L.GANFeatLoss(opt)
+
+    fake = out.detach().clone().requires_grad_()
+    tag, orient, real = b["input_tag"], b["orient"], b["image_tag"]
+    d_in = torch.cat([torch.cat([tag, orient, fake], 1), torch.cat([tag, orient, real], 1)], 0)
+    preds = D(d_in)
+    pf = [[t[: t.size(0) // 2] for t in p] for p in preds]
+    pr = [[t[t.size(0) // 2:] for t in p] for p in preds]
+    label = tag[:, 1:2]
+    l_gan = gan(pf, True, for_discriminator=False, label=label)
+    l_feat = feat(pf, pr, label)
+    weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+    xf, yf = V(fake), V(real)
+    l_vgg = sum(w * torch.nn.functional.l1_loss(a, c.detach()) for w, a, c in zip(weights, xf, yf)) * opt.lambda_vgg
+    (l_gan + l_feat + l_vgg).sum().backward()
+    l_dfake = gan(pf, False, for_discriminator=True, label=label)
+    l_dreal = gan(pr, True, for_discriminator=True, label=label)
+    d = {"loss.GAN": np.array(l_gan.detach()), "loss.GAN_Feat": np.array(l_feat.detach()), "loss.VGG": np.array(l_vgg.detach()),
+         "loss.D_Fake": np.array(l_dfake.detach()), "loss.D_real": np.array(l_dreal.detach()),
+         "dfake": fake.grad.numpy()}
+    for i, p in enumerate(preds):
+        d["pred.%d" % i] = p[-1].detach().numpy()
+        for j, t in enumerate(p[:-1]):
+            d["featstat.%d.%d" % (i, j)] = stats(t)
+    for i, t in enumerate(xf):
+        d["vggstat.%d" % i] = stats(t)
+    d["vgg.relu5_1"] = xf[4].detach().numpy()
+    dn, dnorms = [], []
+    for k, p in D.named_parameters():
+        dn.append(k)
+        dnorms.append(-1.0 if p.grad is None else p.grad.double().norm().item())
+    d["d_grad_norms"] = np.array(dnorms)
+    d["d_buf.discriminator_0.model1.0.0.weight_u"] = D.state_dict()["discriminator_0.model1.0.0.weight_u"].numpy()
+    np.savez_compressed(os.path.join(OUT, "discriminator_vgg_ngf16_c128.npz"), **d)
+    with open(os.path.join(OUT, "discriminator_param_names.json"), "w") as fh:
+        json.dump(dn, fh)
+
+    # ---- state_dict contracts at the BASELINE width (keys + shapes only) ----------------------
+    opt64 = R.make_opt()
+    keys = {"G": {k: list(v.shape) for k, v in R.build_generator(opt64).state_dict().items()},
+            "D": {k: list(v.shape) for k, v in R.build_discriminator(opt64).state_dict().items()},
+            "VGG": {k: list(v.shape) for k, v in V.state_dict().items()}}
+    with open(os.path.join(OUT, "state_dict_contract.json"), "w") as fh:
+        json.dump(keys, fh)
+    with open(os.path.join(OUT, "config.json"), "w") as fh:
+        json.dump(CFG, fh)
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
