@@ -113,7 +113,7 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    losses = {k: float(v.float().mean()) for k, v in trainer.get_latest_losses().items()}
+    losses = {k: float(v.detach().float().mean()) for k, v in trainer.get_latest_losses().items()}
 
     roof = None
     if rank == 0 and not a.no_roofline:

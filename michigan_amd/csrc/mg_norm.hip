@@ -16,14 +16,18 @@ constexpr int NTHR = 256;
 
 struct StatGeom { int tpr; int rpb; int nchunks; int64_t chunk; };
 
-static inline StatGeom stat_geom(int64_t P, int C)
+static inline StatGeom stat_geom(int G, int64_t P, int C)
 {
     StatGeom g;
     const int c4 = C / 4;
     g.tpr = c4 < NTHR ? c4 : NTHR;
     g.rpb = NTHR / g.tpr;
-    int64_t want = (P + (int64_t)g.rpb * 16 - 1) / ((int64_t)g.rpb * 16);   // >= 16 rows per thread
-    if (want > 2048) want = 2048;
+    // enough stage-1 blocks to fill 256 CUs a few times over (G groups share the budget), but at
+    // least 16 rows per thread and at most 512 partials per group for the stage-2 tree.
+    int64_t want = (1536 + G - 1) / G;
+    const int64_t cap = (P + (int64_t)g.rpb * 16 - 1) / ((int64_t)g.rpb * 16);
+    if (want > cap) want = cap;
+    if (want > 512) want = 512;
     if (want < 1) want = 1;
     g.chunk = (P + want - 1) / want;
     g.nchunks = (int)((P + g.chunk - 1) / g.chunk);
@@ -107,15 +111,26 @@ __global__ __launch_bounds__(NTHR) void reduce_stage1(
     }
 }
 
-__global__ void reduce_stage2(const float* __restrict__ partial, float* __restrict__ sums, int nchunks, int C2)
+// stage 2: one 256-thread block per 32 consecutive outputs; 8 thread rows split the chunks,
+// fp64 accumulation, fixed order (deterministic).
+__global__ __launch_bounds__(256) void reduce_stage2(const float* __restrict__ partial, float* __restrict__ sums, int nchunks, int C2)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double red[256];
+    const int cl = threadIdx.x & 31, kk = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + cl;
     const int g = blockIdx.y;
-    if (i >= C2) return;
     double a = 0.0;
-    const float* p = partial + (size_t)g * nchunks * C2 + i;
-    for (int k = 0; k < nchunks; ++k) a += (double)p[(size_t)k * C2];
-    sums[(size_t)g * C2 + i] = (float)a;
+    if (i < C2) {
+        const float* p = partial + (size_t)g * nchunks * C2 + i;
+        for (int k = kk; k < nchunks; k += 8) a += (double)p[(size_t)k * C2];
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (kk == 0 && i < C2) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) a += red[r * 32 + cl];
+        sums[(size_t)g * C2 + i] = (float)a;
+    }
 }
 
 template <typename T>
@@ -172,13 +187,13 @@ template <typename T, int MODE>
 int run_reduce(const void* x, const void* dh, const void* h, const void* g1, const float* mean, const float* rstd,
                void* dgb, int G, int64_t P, int C, float* sums, void* partial, int act, float slope, hipStream_t st)
 {
-    const StatGeom sg = stat_geom(P, C);
+    const StatGeom sg = stat_geom(G, P, C);
     dim3 grid(sg.nchunks, G);
     hipLaunchKernelGGL((reduce_stage1<T, MODE>), grid, dim3(NTHR), 0, st,
                        (const T*)x, (const T*)dh, (const T*)h, (const T*)g1, mean, rstd, (T*)dgb,
                        (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, act, slope);
     MG_CHECK_LAUNCH("reduce_stage1");
-    dim3 grid2((2 * C + 255) / 256, G);
+    dim3 grid2((2 * C + 31) / 32, G);
     hipLaunchKernelGGL(reduce_stage2, grid2, dim3(256), 0, st, (const float*)partial, sums, sg.nchunks, 2 * C);
     MG_CHECK_LAUNCH("reduce_stage2");
     return MG_OK;
@@ -193,7 +208,7 @@ int run_reduce(const void* x, const void* dh, const void* h, const void* g1, con
 extern "C" int64_t mg_stats_workspace(int32_t G, int64_t P, int32_t C)
 {
     if (G <= 0 || P <= 0 || C <= 0) return 0;
-    const StatGeom sg = stat_geom(P, C);
+    const StatGeom sg = stat_geom(G, P, C);
     return (int64_t)G * sg.nchunks * 2 * C * (int64_t)sizeof(float);
 }
 

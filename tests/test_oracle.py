@@ -1,0 +1,113 @@
+"""CPU: pin the oracle (oracle/michigan_oracle.py).
+  * against the golden vectors produced by the reference itself (always; these travel);
+  * against the reference's own modules imported from /root/reference (only where that tree exists)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import parity_utils as PU
+from oracle import michigan_oracle as O
+from oracle import ref_harness as R
+
+needs_ref = pytest.mark.skipif(not R.reference_available(), reason="/root/reference not present (GPU box)")
+
+
+def _leaf(sd):
+    return {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and not k.endswith("_u") and not k.endswith("_v"))
+            for k, v in sd.items()}
+
+
+def _golden_setup():
+    from michigan_amd import networks
+    from michigan_amd.synth import synth_batch, synth_state_dict
+    cfg = PU.load_cfg()
+    opt = PU.small_opt()
+    with torch.device("meta"):
+        tmpl = {k: torch.empty(v.shape, dtype=v.dtype, device="cpu") for k, v in networks.SPADEBGenerator(opt).state_dict().items()}
+    sd = _leaf(synth_state_dict(tmpl, seed=cfg["seed_w"], gain=cfg["gain"]))
+    return cfg, opt, sd, synth_batch(cfg["n"], cfg["crop_size"], seed=cfg["seed_x"])
+
+
+def test_oracle_generator_matches_golden():
+    cfg, opt, sd, b = _golden_setup()
+    g = PU.golden("generator_ngf16_c128.npz")
+    taps, upd = {}, {}
+    random.seed(cfg["seed_py"])
+    out = O.spadeb_generator(sd, opt, b["input_ref"], b["orient"], b["image_ref"], b["input_tag"], b["noise"],
+                             b["image_tag"], True, upd, taps=taps)
+    assert np.abs(out.detach().numpy() - g["out"]).max() < 5e-5
+    for k in g.files:
+        if k.startswith("buf."):
+            assert np.abs(upd[k[4:]].numpy() - g[k]).max() < 1e-5, k
+    gy = torch.randn(out.shape, generator=torch.Generator().manual_seed(99))
+    (out * gy).sum().backward()
+    import json, os
+    names = json.load(open(os.path.join(PU.GOLDEN, "generator_param_names.json")))
+    norms = np.array([(-1.0 if sd[k].grad is None else sd[k].grad.double().norm().item()) for k in names])
+    m = g["grad_norms"] > 0
+    assert ((g["grad_norms"] < 0) == (norms < 0)).all()
+    rel = np.abs(norms - g["grad_norms"])[m] / (g["grad_norms"][m] + 1e-3 * g["grad_norms"][m].max())
+    assert rel.max() < 2e-3
+
+
+@needs_ref
+def test_oracle_matches_reference_modules():
+    from michigan_amd.synth import synth_batch, synth_state_dict
+    opt = R.make_opt(ngf=8, ndf=8, crop_size=64, random_expand_mask=True)
+    G = R.build_generator(opt).train()
+    sd = synth_state_dict(G.state_dict(), seed=21, gain=1.1)
+    G.load_state_dict(sd)
+    b = synth_batch(3, 64, seed=8)
+    random.seed(5)
+    ref = G(b["input_ref"], orient_mask=b["orient"], image_ref=b["image_ref"], input_tag=b["input_tag"],
+            noise=b["noise"], image_tag=b["image_tag"])
+    upd = {}
+    random.seed(5)
+    out = O.spadeb_generator(sd, opt, b["input_ref"], b["orient"], b["image_ref"], b["input_tag"], b["noise"], b["image_tag"], True, upd)
+    assert (out - ref).abs().max().item() < 1e-4
+    new = G.state_dict()
+    assert max((upd[k] - new[k]).abs().max().item() for k in upd) < 1e-5
+    # eval mode (running statistics, no power iteration)
+    G.eval()
+    opt_e = R.make_opt(ngf=8, ndf=8, crop_size=64, isTrain=False)
+    G.opt = opt_e
+    G.backgroud_enc.opt = opt_e
+    with torch.no_grad():
+        ref_e = G(b["input_ref"], orient_mask=b["orient"], image_ref=b["image_ref"], input_tag=b["input_tag"],
+                  noise=b["noise"], image_tag=b["image_tag"])
+        out_e = O.spadeb_generator(new, opt_e, b["input_ref"], b["orient"], b["image_ref"], b["input_tag"], b["noise"], b["image_tag"], False)
+    assert (out_e - ref_e).abs().max().item() < 1e-4
+
+    D = R.build_discriminator(opt).train()
+    sdd = synth_state_dict(D.state_dict(), seed=22)
+    D.load_state_dict(sdd)
+    xin = torch.randn(4, 7, 64, 64)
+    r, o = D(xin), O.multiscale_discriminator(xin, sdd, True, {})
+    assert max((a - c).abs().max().item() for ra, oa in zip(r, o) for a, c in zip(ra, oa)) < 1e-4
+
+    V = R.build_vgg()
+    sdv = synth_state_dict(V.state_dict(), seed=23, gain=1.4)
+    V.load_state_dict(sdv)
+    xi = torch.randn(1, 3, 32, 32)
+    assert max((a - c).abs().max().item() for a, c in zip(V(xi), O.vgg19_features(xi, sdv))) < 1e-4
+
+    L = R.losses()
+    gl, fl = L.GANLoss("hinge", tensor=torch.FloatTensor, opt=opt), L.GANFeatLoss(opt)
+    lab = b["hair"][:2]
+    pf, pr = [[t[:2] for t in p] for p in r], [[t[2:] for t in p] for p in r]
+    assert abs(float(gl(pr, True, True, label=lab) - O.gan_hinge_loss(pr, True, True, lab, opt.wide_edge))) < 1e-6
+    assert abs(float(gl(pf, False, True, label=lab) - O.gan_hinge_loss(pf, False, True, lab, opt.wide_edge))) < 1e-6
+    assert abs(float(gl(pf, True, False, label=lab) - O.gan_hinge_loss(pf, True, False, lab, opt.wide_edge))) < 1e-6
+    assert abs(float(fl(pf, pr, lab) - O.gan_feat_loss(pf, pr, opt.lambda_feat))) < 1e-6
+
+
+@needs_ref
+def test_state_dict_contract_fixture_is_current():
+    """The committed key/shape contract equals what the reference builds today."""
+    import json, os
+    contract = json.load(open(os.path.join(PU.GOLDEN, "state_dict_contract.json")))
+    opt = R.make_opt()
+    assert {k: list(v.shape) for k, v in R.build_generator(opt).state_dict().items()} == contract["G"]
+    assert {k: list(v.shape) for k, v in R.build_discriminator(opt).state_dict().items()} == contract["D"]

@@ -1,0 +1,100 @@
+"""CPU, world_size 2 over gloo: the data-parallel path (cross-rank batch-norm statistics in forward AND
+backward, in-place bucketed gradient averaging in the flat arena, identical Adam updates on every rank)
+reproduces the single-process result on the concatenated batch -- the property sync-BN promises
+(sync_batchnorm/batchnorm.py:219-227).  Runs on the C-ABI contract emulator."""
+import os
+import random
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _one_step(rank, world, port, n_total, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(2)
+    from michigan_amd import _cabi, networks, parallel
+    from michigan_amd.optim import FlatAdam
+    from michigan_amd.synth import synth_batch, synth_state_dict
+    from oracle.cabi_emulator import EmulatorBackend
+    import parity_utils as PU
+    _cabi.set_backend(EmulatorBackend())
+    group = None
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        group = parallel.init()
+        assert group is not None
+    opt = PU.small_opt(ngf=8, crop_size=128)
+    G = networks.SPADEBGenerator(opt).train()
+    G.load_state_dict(synth_state_dict(G.state_dict(), seed=31, gain=1.0))
+    optim = FlatAdam(G.parameters(), lr=1e-3, betas=(0.0, 0.9), bucket_bytes=1 << 18, group=group)
+    full = synth_batch(n_total, 128, seed=17)
+    per = n_total // world
+    b = {k: v[rank * per:(rank + 1) * per] for k, v in full.items()}
+    gy = torch.randn(n_total, 3, 128, 128, generator=torch.Generator().manual_seed(5))[rank * per:(rank + 1) * per]
+    for it in range(2):
+        optim.zero_grad()
+        random.seed(100 + it)
+        out = G(b["input_ref"], orient_mask=b["orient"], image_ref=b["image_ref"], input_tag=b["input_tag"],
+                noise=b["noise"], image_tag=b["image_tag"])
+        ((out * gy).sum() / per).backward()
+        if it == 0:
+            optim.sync_grads()                      # summed over ranks; the 1/world average is applied inside Adam
+            grad0 = (optim.flat_grad / world).numpy().copy()
+            out0 = out.detach().numpy().copy()
+            rm0 = G.state_dict()["up_3.norm_1.param_free_norm.running_mean"].numpy().copy()
+            rv0 = G.state_dict()["head_0.norm_0.param_free_norm.running_var"].numpy().copy()
+        optim.step()
+    res = {"grad0": grad0, "flat": optim.flat.detach().numpy().copy(), "out": out0, "rm": rm0, "rv": rv0}      # numpy: plain pickling
+    q.put((rank, res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_equal_single_process_on_concatenated_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_step, args=(0, 1, 0, 4, q))
+    p.start()
+    _, single = q.get(timeout=600)
+    p.join()
+    port = _free_port()
+    procs = [ctx.Process(target=_one_step, args=(r, 2, port, 4, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    single = {k: torch.from_numpy(v) for k, v in single.items()}
+    got = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in got.items()}
+    for p in procs:
+        p.join()
+        assert p.exitcode == 0
+    # every rank holds the same parameters, equal to the single-process ones
+    assert torch.equal(got[0]["flat"], got[1]["flat"])
+    # averaged gradients (before Adam's sign-like normalisation, which is ill-conditioned where g ~ 0)
+    gscale = single["grad0"].abs().max().item()
+    assert torch.equal(got[0]["grad0"], got[1]["grad0"])
+    assert (got[0]["grad0"] - single["grad0"]).abs().max().item() < 1e-4 * gscale
+    solid = single["grad0"].abs() > 1e-3 * gscale            # parameters whose update direction is well defined
+    assert (got[0]["flat"] - single["flat"])[solid].abs().max().item() < 2e-4
+    # per-sample outputs agree with the big-batch run; running statistics are the global ones
+    out2 = torch.cat([got[0]["out"], got[1]["out"]])
+    assert (out2 - single["out"]).abs().max().item() < 5e-5
+    for k in ("rm", "rv"):
+        assert torch.allclose(got[0][k], got[1][k]) and (got[0][k] - single[k]).abs().max().item() < 1e-5
