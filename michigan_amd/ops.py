@@ -296,14 +296,19 @@ def batch_stats(x: torch.Tensor, eps: float = 1e-5):
         count = x.numel() // c
         sums = channel_sums(x)[0].double()                     # [2, C]
         if SYNC_BN_GROUP is not None:
+            # ONE collective per layer: [sum | sum of squares | element count], fp64, no host sync --
+            # the global count stays a device scalar (ranks may hold different batch sizes).
             import torch.distributed as dist
             packed = torch.cat([sums.reshape(-1), sums.new_tensor([float(count)])])
             dist.all_reduce(packed, group=SYNC_BN_GROUP)
-            sums, count = packed[:-1].reshape(2, c), int(round(packed[-1].item()))
+            sums, count = packed[:-1].reshape(2, c), packed[-1]
+            denom = (count - 1).clamp_min(1.0)
+        else:
+            denom = max(count - 1, 1)
         mean = sums[0] / count
         var = (sums[1] / count - mean * mean).clamp_min_(0.0)
         rstd = torch.rsqrt(var + eps)
-        unbiased = var * (count / max(count - 1, 1))
+        unbiased = var * (count / denom)
         return mean.float(), rstd.float(), unbiased.float(), count
 
 
@@ -366,7 +371,7 @@ class _SpadeFn(torch.autograd.Function):
             if SYNC_BN_GROUP is not None:
                 import torch.distributed as dist
                 dist.all_reduce(sums, group=SYNC_BN_GROUP)
-            s = (sums[0] / float(count)).contiguous()
+            s = (sums[0] / count).float().contiguous()
             dx = torch.empty_like(x)
             be.mg_norm_bwd_apply(_p(dh), _p(h), _p(x), _p(g1), _dt(x), 1, p, c, _p(mean), _p(rstd),
                                  _p(s[0]), _p(s[1]), act, slope, _p(dx), _stream(x))
