@@ -198,6 +198,10 @@ int mg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
 int mg_probe_mfma_layout(float* out /* [3][64][16] */, void* stream);
 int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* out /* [64][4] */, void* stream);
 
+/* Tuning switch for A/B measurements: key 0 = conv pipeline (0 register-staged double buffer,
+ * 1 LDS-DMA three-stage ring, default).  Results are identical either way. */
+int         mg_set_option(int32_t key, int32_t value);
+
 /* sizeof(mg_conv_desc) (which=0) / sizeof(mg_wgrad_desc) (which=1): lets a
  * foreign-language binding check its struct mirror without a GPU. */
 int         mg_sizeof_desc(int32_t which);

@@ -66,6 +66,7 @@ _PROTOS = {
     "mg_adam_step": ([_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp], _i32),
     "mg_probe_mfma_layout": ([_vp, _vp], _i32),
     "mg_probe_tr16": ([_vp, _vp, _vp], _i32),
+    "mg_set_option": ([_i32, _i32], _i32),
     "mg_sizeof_desc": ([_i32], _i32),
     "mg_abi_version": ([], _i32),
     "mg_last_error": ([], ctypes.c_char_p),

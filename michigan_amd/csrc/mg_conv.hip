@@ -16,10 +16,11 @@
 // (exact fp32 fma chain) -- same tiling, same LDS image (64 B of K per row).
 #include "mg_common.h"
 
+int g_mg_conv_pipeline = 1;      // 0 = register-staged double buffer, 1 = LDS-DMA 3-stage ring (mg_set_option(0, v))
+
 namespace {
 
 constexpr int ROWB = 64;    // bytes of K per LDS row and pipeline stage
-constexpr int ROWS = 80;    // padded LDS row stride in bytes
 constexpr int NTHR = 256;
 
 struct ConvK {              // kernel-side view of mg_conv_desc (passed by value)
@@ -32,167 +33,71 @@ struct ConvK {              // kernel-side view of mg_conv_desc (passed by value
     int ntaps, act; float slope;
     int ngemm;              // N*Hj*Wj
     int tiles_m;
+    int tpc;                // taps packed into one 64-byte K chunk (tiny Cin), 1 otherwise
     int tap[MG_MAX_TAPS];   // (dy & 0xffff) | (dx << 16)
 };
 
-template <typename T, int WM, int WN, int MT, int NT, int EPI>
-__global__ __launch_bounds__(NTHR) void conv_taps_kernel(const ConvK d)
+// LDS image shared by both pipelines: rows of 64 bytes of K, NO padding; the four 16-byte pieces of a
+// row are XOR-swizzled with (row >> 2) & 3.  ds_write_b128 (8-lane groups = 2 rows x 4 pieces, bank =
+// addr/4 mod 32) and ds_read_b128 (16-lane groups with rows distinct mod 16, bank = addr/4 mod 64) are
+// both conflict-free with it; the previous 80-byte padded rows made every ds_write_b128 2-way
+// (SQ_LDS_BANK_CONFLICT = 1/3 of SQ_LDS_IDX_ACTIVE, profiles/r01_pmc_conv.txt).
+__device__ __forceinline__ int lds_off(int row, int piece) { return row * ROWB + ((piece ^ ((row >> 2) & 3)) << 4); }
+
+template <typename T, int MT, int NT>
+__device__ __forceinline__ void conv_compute(const unsigned char* As, const unsigned char* Bs, int l31, int hi,
+                                             f32x16_t (&acc)[MT][NT])
 {
-    constexpr bool BF = (sizeof(T) == 2);
-    constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
-    constexpr int EPP = 16 / (int)sizeof(T);        // elements per 16-byte piece
-    constexpr int CH  = ROWB / (int)sizeof(T);      // K elements per chunk
-    constexpr int A_PT = (TM * 4 + NTHR - 1) / NTHR;
-    constexpr int B_PT = (TN * 4) / NTHR;
-    constexpr int STAGE = (TM + TN) * ROWS;
-    static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(EPI == MG_EPI_PLAIN || MT == 2, "SPADE epilogue needs gamma/beta tile pair");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, hi = lane >> 5;
-
-    // XCD-aware (bijective) block -> tile map: blocks of one XCD (b % 8) get a
-    // contiguous tile range so neighbouring pixel tiles share that XCD's L2.
-    int tile;
-    {
-        const int nblk = gridDim.x, b = blockIdx.x;
-        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
-        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    }
-    const int tm = tile % d.tiles_m, tn = tile / d.tiles_m;
-    const int m0 = tm * TM;
-    const int q0 = tn * TN;
-
-    const T* __restrict__ In = reinterpret_cast<const T*>(d.in);
-    const T* __restrict__ Wt = reinterpret_cast<const T*>(d.wt);
-    const int HWj = d.Hj * d.Wj;
-
-    // ---- per-thread staging assignment (fixed over the K loop) ------------
-    const int piece = tid & 3;
-    const int srow  = tid >> 2;                       // 0..63
-    int b_n[B_PT], b_y[B_PT], b_x[B_PT];
+    // As/Bs point at this wave's first row; the lane's rows are l31 + 32*t, so (row >> 2) & 3 == (l31 >> 2) & 3
+    const int sw = (l31 >> 2) & 3;
+    if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int i = 0; i < B_PT; ++i) {
-        const int q = q0 + srow + i * 64;
-        if (q < d.ngemm) {
-            const int n = q / HWj, r = q - n * HWj;
-            const int jy = r / d.Wj, jx = r - jy * d.Wj;
-            b_n[i] = n; b_y[i] = jy * d.isy; b_x[i] = jx * d.isx;
-        } else { b_n[i] = 0; b_y[i] = -(1 << 20); b_x[i] = 0; }
-    }
-
-    uint4 ra[A_PT], rb[B_PT];
-    const int nchunk = (d.Cin + CH - 1) / CH;
-    const int nk = d.ntaps * nchunk;
-
-    auto gload = [&](int tap, int chunk) {
-        const int c = chunk * CH + piece * EPP;
-        const bool cv = c < d.Cin;
-        const int tp = d.tap[tap];
-        const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t a[MT], b[NT];
+            const int po = ((ks * 2 + hi) ^ sw) << 4;
 #pragma unroll
-        for (int i = 0; i < A_PT; ++i) {
-            const int row = srow + i * 64;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < TM && cv)
-                v = *reinterpret_cast<const uint4*>(Wt + ((size_t)(tap * d.CoutP + m0 + row) * d.Cin + c));
-            ra[i] = v;
-        }
+            for (int mt = 0; mt < MT; ++mt)
+                a[mt] = *reinterpret_cast<const bf16x8_t*>(As + (mt * 32 + l31) * ROWB + po);
 #pragma unroll
-        for (int i = 0; i < B_PT; ++i) {
-            const int iy = b_y[i] + dy, ix = b_x[i] + dx;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (cv && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win)
-                v = *reinterpret_cast<const uint4*>(In + ((size_t)((b_n[i] * d.Hin + iy) * d.Win + ix) * d.Cin + c));
-            rb[i] = v;
-        }
-    };
-    auto lstore = [&](int s) {
-        unsigned char* base = smem + s * STAGE;
+            for (int nt = 0; nt < NT; ++nt)
+                b[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + (nt * 32 + l31) * ROWB + po);
 #pragma unroll
-        for (int i = 0; i < A_PT; ++i) {
-            const int row = srow + i * 64;
-            if (row < TM) *reinterpret_cast<uint4*>(base + row * ROWS + piece * 16) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < B_PT; ++i) {
-            const int row = srow + i * 64;
-            *reinterpret_cast<uint4*>(base + (TM + row) * ROWS + piece * 16) = rb[i];
-        }
-    };
-
-    f32x16_t acc[MT][NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-    auto compute = [&](int s) {
-        const unsigned char* As = smem + s * STAGE + (wm * MT * 32 + l31) * ROWS;
-        const unsigned char* Bs = smem + s * STAGE + (TM + wn * NT * 32 + l31) * ROWS;
-        if constexpr (BF) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8_t a[MT], b[NT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    a[mt] = *reinterpret_cast<const bf16x8_t*>(As + mt * 32 * ROWS + ks * 32 + hi * 16);
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    b[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + nt * 32 * ROWS + ks * 32 + hi * 16);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
-            }
-        } else {
-            // lane (row, hi) owns K elements hi*8 .. hi*8+7 of the 16-float chunk; MFMA j
-            // consumes element j of both halves -- any K permutation is legal as long as
-            // A and B use the same one.
-            f32x4_t a[MT][2], b[NT][2];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                a[mt][0] = *reinterpret_cast<const f32x4_t*>(As + mt * 32 * ROWS + hi * 32);
-                a[mt][1] = *reinterpret_cast<const f32x4_t*>(As + mt * 32 * ROWS + hi * 32 + 16);
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                b[nt][0] = *reinterpret_cast<const f32x4_t*>(Bs + nt * 32 * ROWS + hi * 32);
-                b[nt][1] = *reinterpret_cast<const f32x4_t*>(Bs + nt * 32 * ROWS + hi * 32 + 16);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j >> 2][j & 3], b[nt][j >> 2][j & 3],
-                                                                           acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
         }
-    };
-
-    // ---- main loop: double-buffered, one barrier per chunk -----------------
-    int tap = 0, chunk = 0;
-    gload(0, 0);
-    lstore(0);
-    __syncthreads();
-    for (int it = 0; it < nk; ++it) {
-        const bool more = (it + 1 < nk);
-        if (more) {
-            if (++chunk == nchunk) { chunk = 0; ++tap; }
-            gload(tap, chunk);
+    } else {
+        // lane (row, hi) owns K elements hi*8 .. hi*8+7 of the 16-float chunk; MFMA j consumes element j
+        // of both halves -- any K permutation is legal as long as A and B use the same one.
+        f32x4_t a[MT][2], b[NT][2];
+        const int p0 = ((hi * 2) ^ sw) << 4, p1 = ((hi * 2 + 1) ^ sw) << 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            a[mt][0] = *reinterpret_cast<const f32x4_t*>(As + (mt * 32 + l31) * ROWB + p0);
+            a[mt][1] = *reinterpret_cast<const f32x4_t*>(As + (mt * 32 + l31) * ROWB + p1);
         }
-        compute(it & 1);
-        if (more) lstore((it + 1) & 1);
-        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            b[nt][0] = *reinterpret_cast<const f32x4_t*>(Bs + (nt * 32 + l31) * ROWB + p0);
+            b[nt][1] = *reinterpret_cast<const f32x4_t*>(Bs + (nt * 32 + l31) * ROWB + p1);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j >> 2][j & 3], b[nt][j >> 2][j & 3],
+                                                                       acc[mt][nt], 0, 0, 0);
     }
+}
 
+template <typename T, int MT, int NT, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT][NT], int m0, int q0,
+                                              int wm, int wn, int l31, int hi)
+{
+    const int HWj = d.Hj * d.Wj;
     // ---- epilogue -----------------------------------------------------------
     T* __restrict__ Out = reinterpret_cast<T*>(d.out);
 #pragma unroll
@@ -280,18 +185,304 @@ __global__ __launch_bounds__(NTHR) void conv_taps_kernel(const ConvK d)
     }
 }
 
+template <typename T, int WM, int WN, int MT, int NT, int EPI, bool PACK>
+__global__ __launch_bounds__(NTHR) void conv_taps_kernel(const ConvK d)
+{
+    constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
+    constexpr int EPP = 16 / (int)sizeof(T);        // elements per 16-byte piece
+    constexpr int CH  = ROWB / (int)sizeof(T);      // K elements per chunk
+    constexpr int A_PT = (TM * 4 + NTHR - 1) / NTHR;
+    constexpr int B_PT = (TN * 4) / NTHR;
+    constexpr int STAGE = (TM + TN) * ROWB;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(EPI == MG_EPI_PLAIN || MT == 2, "SPADE epilogue needs gamma/beta tile pair");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // XCD-aware (bijective) block -> tile map: blocks of one XCD (b % 8) get a
+    // contiguous tile range so neighbouring pixel tiles share that XCD's L2.
+    int tile;
+    {
+        const int nblk = gridDim.x, b = blockIdx.x;
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int tm = tile % d.tiles_m, tn = tile / d.tiles_m;
+    const int m0 = tm * TM;
+    const int q0 = tn * TN;
+
+    const T* __restrict__ In = reinterpret_cast<const T*>(d.in);
+    const T* __restrict__ Wt = reinterpret_cast<const T*>(d.wt);
+    const int HWj = d.Hj * d.Wj;
+
+    // ---- per-thread staging assignment (fixed over the K loop) ------------
+    const int piece = tid & 3;
+    const int srow  = tid >> 2;                       // 0..63
+    int b_n[B_PT], b_y[B_PT], b_x[B_PT];
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) {
+        const int q = q0 + srow + i * 64;
+        if (q < d.ngemm) {
+            const int n = q / HWj, r = q - n * HWj;
+            const int jy = r / d.Wj, jx = r - jy * d.Wj;
+            b_n[i] = n; b_y[i] = jy * d.isy; b_x[i] = jx * d.isx;
+        } else { b_n[i] = 0; b_y[i] = -(1 << 20); b_x[i] = 0; }
+    }
+
+    uint4 ra[A_PT], rb[B_PT];
+    const int nchunk = PACK ? 1 : (d.Cin + CH - 1) / CH;
+    const int nk = PACK ? (d.ntaps + d.tpc - 1) / d.tpc : d.ntaps * nchunk;
+    // PACK (Cin < one chunk): a 64-byte chunk holds tpc whole taps; this thread's piece sits in tap
+    // (it * tpc + ptap) at channel pch -- 4x (bf16, Cin 8) fewer K iterations for the first-layer convs.
+    const int ptap = PACK ? (piece * EPP) / d.Cin : 0;
+    const int pch  = PACK ? (piece * EPP) % d.Cin : 0;
+
+    auto gload = [&](int tap, int chunk) {
+        if constexpr (PACK) { tap = tap * d.tpc + ptap; }
+        const int c = PACK ? pch : chunk * CH + piece * EPP;
+        const bool cv = PACK ? (tap < d.ntaps) : (c < d.Cin);
+        const int tp = d.tap[cv || !PACK ? tap : 0];
+        const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
+#pragma unroll
+        for (int i = 0; i < A_PT; ++i) {
+            const int row = srow + i * 64;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < TM && cv)
+                v = *reinterpret_cast<const uint4*>(Wt + ((size_t)(tap * d.CoutP + m0 + row) * d.Cin + c));
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PT; ++i) {
+            const int iy = b_y[i] + dy, ix = b_x[i] + dx;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (cv && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win)
+                v = *reinterpret_cast<const uint4*>(In + ((size_t)((b_n[i] * d.Hin + iy) * d.Win + ix) * d.Cin + c));
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&](int s) {
+        unsigned char* base = smem + s * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_PT; ++i) {
+            const int row = srow + i * 64;
+            if (row < TM) *reinterpret_cast<uint4*>(base + lds_off(row, piece)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_PT; ++i) {
+            const int row = srow + i * 64;
+            *reinterpret_cast<uint4*>(base + TM * ROWB + lds_off(row, piece)) = rb[i];
+        }
+    };
+
+    f32x16_t acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    auto compute = [&](int s) {
+        conv_compute<T, MT, NT>(smem + s * STAGE + (wm * MT * 32) * ROWB, smem + s * STAGE + (TM + wn * NT * 32) * ROWB,
+                                l31, hi, acc);
+    };
+
+    // ---- main loop: double-buffered, one barrier per chunk -----------------
+    int tap = 0, chunk = 0;
+    gload(0, 0);
+    lstore(0);
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+        const bool more = (it + 1 < nk);
+        if (more) {
+            if (++chunk == nchunk) { chunk = 0; ++tap; }     // PACK: nchunk == 1, `tap` counts chunk groups
+            gload(tap, chunk);
+        }
+        compute(it & 1);
+        if (more) lstore((it + 1) & 1);
+        __syncthreads();
+    }
+
+    conv_epilogue<T, MT, NT, EPI>(d, acc, m0, q0, wm, wn, l31, hi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pipeline 2: LDS-DMA (global_load_lds_dwordx4) into a 3-stage ring, two K chunks in flight.
+//
+// No staging VGPRs and no ds_write: each wave-instruction drops 64 lanes x 16 B = 16 rows x 64 B straight
+// into LDS (destination = wave-uniform base + lane*16, so the XOR swizzle is applied on the SOURCE piece
+// each lane fetches); out-of-image taps, tail pixels and tail channels fetch from a 64-byte block of
+// zeros instead of being predicated off (a masked lane would leave stale LDS bytes).  The loads are
+// inline asm so hipcc neither counts them nor drains them with vmcnt(0) before every ds_read; the
+// schedule per K chunk is:  wait(vmcnt = one stage of this wave's loads still in flight) -> s_barrier
+// -> issue chunk it+2 into the slot consumed at it-1 -> MFMAs on chunk it.
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(64))) unsigned char g_mg_zeros[64];
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <typename T, int WM, int WN, int MT, int NT, int EPI, bool PACK>
+__global__ __launch_bounds__(NTHR) void conv_taps_glds_kernel(const ConvK d)
+{
+    constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
+    constexpr int EPP = 16 / (int)sizeof(T);
+    constexpr int CH  = ROWB / (int)sizeof(T);
+    constexpr int A_IPS = TM / 64, B_IPS = TN / 64;          // 1 KiB wave-instructions per stage per wave
+    constexpr int IPS = A_IPS + B_IPS;
+    constexpr int NS = 3;
+    constexpr int STAGE = (TM + TN) * ROWB;
+    static_assert(WM * WN == 4 && TM % 64 == 0 && TN % 64 == 0, "tile must be whole 16-row blocks per wave");
+    static_assert(IPS == 4 || IPS == 5, "vmcnt immediates below assume 4 or 5 loads per stage");
+    static_assert(EPI == MG_EPI_PLAIN || MT == 2, "SPADE epilogue needs gamma/beta tile pair");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    int tile;
+    {
+        const int nblk = gridDim.x, b = blockIdx.x;
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int tm = tile % d.tiles_m, tn = tile / d.tiles_m;
+    const int m0 = tm * TM;
+    const int q0 = tn * TN;
+
+    const T* __restrict__ In = reinterpret_cast<const T*>(d.in);
+    const T* __restrict__ Wt = reinterpret_cast<const T*>(d.wt);
+    const int HWj = d.Hj * d.Wj;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    // lane -> (row inside its 16-row block, LOGICAL piece it must fetch so that the physical slot
+    // lane&3 holds piece ^ ((row>>2)&3); all block bases are multiples of 16 rows so (row>>2)&3 == (lane>>4)&3)
+    const int lrow = lane >> 2;
+    const int piece = (lane & 3) ^ ((lane >> 4) & 3);
+    int b_n[B_IPS], b_y[B_IPS], b_x[B_IPS];
+#pragma unroll
+    for (int j = 0; j < B_IPS; ++j) {
+        const int q = q0 + (wave + 4 * j) * 16 + lrow;
+        if (q < d.ngemm) {
+            const int n = q / HWj, r = q - n * HWj;
+            const int jy = r / d.Wj, jx = r - jy * d.Wj;
+            b_n[j] = n; b_y[j] = jy * d.isy; b_x[j] = jx * d.isx;
+        } else { b_n[j] = 0; b_y[j] = -(1 << 20); b_x[j] = 0; }
+    }
+
+    const int nchunk = PACK ? 1 : (d.Cin + CH - 1) / CH;
+    const int nk = PACK ? (d.ntaps + d.tpc - 1) / d.tpc : d.ntaps * nchunk;
+    const int ptap = PACK ? (piece * EPP) / d.Cin : 0;
+    const int pch  = PACK ? (piece * EPP) % d.Cin : 0;
+
+    auto issue = [&](int stage, int tap, int chunk) {
+        if constexpr (PACK) { tap = tap * d.tpc + ptap; }
+        const int c = PACK ? pch : chunk * CH + piece * EPP;
+        const bool cv = PACK ? (tap < d.ntaps) : (c < d.Cin);
+        const int tp = d.tap[cv || !PACK ? tap : 0];
+        const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
+        const unsigned sbase = lds0 + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < A_IPS; ++j) {
+            const int blk = wave + 4 * j;
+            const void* src = g_mg_zeros;
+            if (cv) src = Wt + ((size_t)(tap * d.CoutP + m0 + blk * 16 + lrow) * d.Cin + c);
+            glds16(src, __builtin_amdgcn_readfirstlane(sbase + blk * 1024));
+        }
+#pragma unroll
+        for (int j = 0; j < B_IPS; ++j) {
+            const int blk = wave + 4 * j;
+            const int iy = b_y[j] + dy, ix = b_x[j] + dx;
+            const void* src = g_mg_zeros;
+            if (cv && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win)
+                src = In + ((size_t)((b_n[j] * d.Hin + iy) * d.Win + ix) * d.Cin + c);
+            glds16(src, __builtin_amdgcn_readfirstlane(sbase + TM * ROWB + blk * 1024));
+        }
+    };
+
+    f32x16_t acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // prologue: chunks 0 and 1 in flight
+    int tap = 0, chunk = 0;                 // position of the NEXT chunk to issue
+    auto advance = [&]() { if (++chunk == nchunk) { chunk = 0; ++tap; } };
+    issue(0, tap, chunk); advance();
+    if (nk > 1) { issue(1, tap, chunk); advance(); }
+
+    int slot = 0, islot = 2;                // ring slot of chunk `it`, slot chunk it+2 goes to
+    for (int it = 0; it < nk; ++it) {
+        if (it + 1 < nk) {
+            if constexpr (IPS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else                    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();       // every wave's part of chunk `it` has landed; chunk it-1 fully consumed
+        if (it + 2 < nk) { issue(islot, tap, chunk); advance(); }
+        conv_compute<T, MT, NT>(smem + slot * STAGE + (wm * MT * 32) * ROWB,
+                                smem + slot * STAGE + (TM + wn * NT * 32) * ROWB, l31, hi, acc);
+        slot = (slot == NS - 1) ? 0 : slot + 1;
+        islot = (islot == NS - 1) ? 0 : islot + 1;
+    }
+
+    conv_epilogue<T, MT, NT, EPI>(d, acc, m0, q0, wm, wn, l31, hi);
+}
+
+template <typename T, int WM, int WN, int MT, int NT, int EPI, bool PACK>
+int launch_conv_p(ConvK& k, hipStream_t st);
+
 template <typename T, int WM, int WN, int MT, int NT, int EPI>
 int launch_conv(ConvK& k, hipStream_t st)
+{
+    constexpr int CH = ROWB / (int)sizeof(T);
+    k.tpc = (k.Cin < CH && CH % k.Cin == 0) ? CH / k.Cin : 1;
+    if constexpr (EPI == MG_EPI_PLAIN) {
+        if (k.tpc > 1) return launch_conv_p<T, WM, WN, MT, NT, EPI, true>(k, st);
+    }
+    k.tpc = 1;
+    return launch_conv_p<T, WM, WN, MT, NT, EPI, false>(k, st);
+}
+
+template <typename T, int WM, int WN, int MT, int NT, int EPI, bool PACK>
+int launch_conv_p(ConvK& k, hipStream_t st)
 {
     constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
     k.tiles_m = (k.Cout_gemm + TM - 1) / TM;
     const int tiles_n = (k.ngemm + TN - 1) / TN;
     if (k.tiles_m * TM > k.CoutP)
         return mg_fail(MG_ERR_ARG, "mg_conv_taps: CoutP=%d too small for Cout_gemm=%d (tile %d)", k.CoutP, k.Cout_gemm, TM);
-    const size_t lds = 2 * (size_t)(TM + TN) * ROWS;
     const long nblk = (long)k.tiles_m * tiles_n;
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_taps: bad grid %ld", nblk);
-    hipLaunchKernelGGL((conv_taps_kernel<T, WM, WN, MT, NT, EPI>), dim3((unsigned)nblk), dim3(NTHR), lds, st, k);
+    if constexpr (TM % 64 == 0) {
+        if (g_mg_conv_pipeline == 1) {
+            const size_t lds3 = 3 * (size_t)(TM + TN) * ROWB;
+            hipLaunchKernelGGL((conv_taps_glds_kernel<T, WM, WN, MT, NT, EPI, PACK>), dim3((unsigned)nblk), dim3(NTHR), lds3, st, k);
+            MG_CHECK_LAUNCH("mg_conv_taps(glds)");
+            return MG_OK;
+        }
+    }
+    const size_t lds = 2 * (size_t)(TM + TN) * ROWB;
+    hipLaunchKernelGGL((conv_taps_kernel<T, WM, WN, MT, NT, EPI, PACK>), dim3((unsigned)nblk), dim3(NTHR), lds, st, k);
     MG_CHECK_LAUNCH("mg_conv_taps");
     return MG_OK;
 }
@@ -338,9 +529,15 @@ extern "C" int mg_conv_taps(const mg_conv_desc* d, void* stream)
     k.Hj = d->Hj; k.Wj = d->Wj; k.isy = d->isy; k.isx = d->isx;
     k.osy = d->osy; k.osx = d->osx; k.ooy = d->ooy; k.oox = d->oox;
     k.ntaps = d->ntaps; k.act = d->act; k.slope = d->slope;
-    k.ngemm = d->N * d->Hj * d->Wj; k.tiles_m = 0;
+    k.ngemm = d->N * d->Hj * d->Wj; k.tiles_m = 0; k.tpc = 1;
     for (int t = 0; t < MG_MAX_TAPS; ++t)
         k.tap[t] = t < d->ntaps ? (int)((((uint32_t)(int)d->tap_dy[t]) & 0xffffu) | (((uint32_t)(int)d->tap_dx[t]) << 16)) : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     return d->dtype == MG_BF16 ? dispatch_conv<uint16_t>(k, d->epilogue, st) : dispatch_conv<float>(k, d->epilogue, st);
+}
+
+extern "C" int mg_set_option(int32_t key, int32_t value)
+{
+    if (key == 0 && (value == 0 || value == 1)) { g_mg_conv_pipeline = value; return MG_OK; }
+    return mg_fail(MG_ERR_ARG, "mg_set_option: unknown key/value %d/%d", key, value);
 }

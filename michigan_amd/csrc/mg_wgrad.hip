@@ -24,6 +24,7 @@ struct WgK {
     int K;            // N*Hj*Wj
     int kper;         // pixels per split (multiple of KP)
     int tiles_m, tiles_n, splitk;
+    int tpt;          // taps packed into one 128-wide N tile (Cin < 128 and 128 % Cin == 0), else 1
     int tap[MG_MAX_TAPS];
 };
 
@@ -52,17 +53,18 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgK d)
         const int q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
+    // N tiles: tpt == 1 -> (tap, 128-channel slice); tpt > 1 -> groups of tpt taps x all Cin channels
+    const int ngroups = (d.ntaps + d.tpt - 1) / d.tpt;
     const int tm = tile % d.tiles_m;  tile /= d.tiles_m;
     const int tn = tile % d.tiles_n;  tile /= d.tiles_n;
-    const int tap = tile % d.ntaps;
-    const int split = tile / d.ntaps;
+    const int tg = tile % ngroups;
+    const int split = tile / ngroups;
     const int m0 = tm * 128, n0 = tn * 128;
+    const int tap0 = tg * d.tpt;
     const int kbeg = split * d.kper;
     const int kend = min(d.K, kbeg + d.kper);
     if (kbeg >= kend) return;
 
-    const int tp = d.tap[tap];
-    const int tdy = (int)(short)(tp & 0xffff), tdx = tp >> 16;
 
     const T* __restrict__ X  = reinterpret_cast<const T*>(d.x);
     const T* __restrict__ DY = reinterpret_cast<const T*>(d.dy);
@@ -70,8 +72,14 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgK d)
 
     const int piece = tid % PPR, prow = tid / PPR;
     const int ca = m0 + piece * EPP;      // dy channel of this thread's piece
-    const int cb = n0 + piece * EPP;      // x channel of this thread's piece
-    const bool cav = ca < d.Cg, cbv = cb < d.Cin;
+    const bool cav = ca < d.Cg;
+    // x side: this thread's piece belongs to tap `mytap`, channels cb..cb+EPP-1 (loop invariant)
+    int mytap, cb;
+    if (d.tpt > 1) { const int e = piece * EPP; mytap = tap0 + e / d.Cin; cb = e % d.Cin; }
+    else           { mytap = tap0; cb = n0 + piece * EPP; }
+    const bool cbv = (mytap < d.ntaps) && (cb < d.Cin);
+    const int tp = d.tap[mytap < d.ntaps ? mytap : 0];
+    const int tdy = (int)(short)(tp & 0xffff), tdx = tp >> 16;
 
     uint4 ra[NPASS], rb[NPASS];
     auto gload = [&](int k0) {
@@ -194,8 +202,11 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgK d)
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int ci = n0 + wn * 64 + nt * 32 + l31;
-            if (ci >= d.Cin) continue;
+            const int nn = wn * 64 + nt * 32 + l31;            // column inside the N tile
+            int tap, ci;
+            if (d.tpt > 1) { tap = tap0 + nn / d.Cin; ci = nn % d.Cin; }
+            else           { tap = tap0; ci = n0 + nn; }
+            if (tap >= d.ntaps || ci >= d.Cin) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -212,8 +223,9 @@ int launch_wgrad(WgK& k, hipStream_t st)
     constexpr int KP = BF ? 32 : 16;
     constexpr int RS = BF ? 320 : 528;
     k.tiles_m = (k.Cg + 127) / 128;
-    k.tiles_n = (k.Cin + 127) / 128;
-    const long base = (long)k.tiles_m * k.tiles_n * k.ntaps;
+    k.tpt = (k.Cin < 128 && 128 % k.Cin == 0) ? 128 / k.Cin : 1;
+    k.tiles_n = k.tpt > 1 ? 1 : (k.Cin + 127) / 128;
+    const long base = (long)k.tiles_m * k.tiles_n * ((k.ntaps + k.tpt - 1) / k.tpt);
     int S = k.splitk;
     if (S <= 0) {
         S = (int)((1536 + base - 1) / base);                 // ~6 workgroups per CU in flight
@@ -248,7 +260,7 @@ extern "C" int mg_conv_wgrad(const mg_wgrad_desc* d, void* stream)
     k.x = d->x; k.dy = d->dy; k.dw = d->dw;
     k.N = d->N; k.Hin = d->Hin; k.Win = d->Win; k.Cin = d->Cin;
     k.Hj = d->Hj; k.Wj = d->Wj; k.Cg = d->Cg; k.isy = d->isy; k.isx = d->isx; k.ntaps = d->ntaps;
-    k.K = d->N * d->Hj * d->Wj; k.splitk = d->splitk; k.kper = 0; k.tiles_m = k.tiles_n = 0;
+    k.K = d->N * d->Hj * d->Wj; k.splitk = d->splitk; k.kper = 0; k.tiles_m = k.tiles_n = 0; k.tpt = 1;
     for (int t = 0; t < MG_MAX_TAPS; ++t)
         k.tap[t] = t < d->ntaps ? (int)((((uint32_t)(int)d->tap_dy[t]) & 0xffffu) | (((uint32_t)(int)d->tap_dx[t]) << 16)) : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -89,6 +89,9 @@ CONV_CASES = [
     (64, 128, 4, 2, 0, 18, 18, 1),      # 4x4 s2 on reflect-padded input
     (24, 40, 3, 2, 1, 16, 16, 2),       # partial-conv trunk 3x3 s2
     (1024, 512, 1, 1, 0, 8, 8, 2),      # conv_s 1x1
+    (16, 32, 3, 1, 1, 12, 12, 2),       # packed taps: 2 (bf16) taps per K chunk, 8 taps per wgrad N tile
+    (32, 64, 3, 1, 1, 10, 10, 1),       # Cin == one bf16 chunk; wgrad packs 4 taps per tile
+    (8, 128, 7, 1, 3, 14, 14, 1),       # 49 taps, packed (ragged last chunk: 49 = 12*4 + 1)
 ]
 
 

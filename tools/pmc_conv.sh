@@ -1,0 +1,27 @@
+#!/bin/bash
+# PMC passes over the conv microbenchmark (run on the GPU box): tools/pmc_conv.sh <shape-substring> <dtype>
+set -u
+SHAPE=${1:-spade_gb_128x2*128@512}; DT=${2:-bf16}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc
+mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+run() { # name counters...
+  local name=$1; shift
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o p -- python $GRAFT_REPO_ROOT/tools/bench_kernels.py --n 4 --dtype $DT --only "$SHAPE" > $OUT/$name.log 2>&1
+  python - <<PY
+import csv, collections, glob
+f = glob.glob("$OUT/$name/*counter_collection.csv")
+if not f: print("$name: no counter file", open("$OUT/$name.log").read()[-600:]); raise SystemExit
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+for r in csv.DictReader(open(f[0])):
+    k = r["Kernel_Name"][:60]
+    agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
+    cnt[(k, r["Counter_Name"])] += 1
+for k, d in agg.items():
+    if "conv_taps" in k or "wgrad" in k:
+        print("$name", k, {c: round(v / cnt[(k, c)], 1) for c, v in d.items()})
+PY
+}
+run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16
+run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU
+run tcc FETCH_SIZE
+run tcw WRITE_SIZE GRBM_GUI_ACTIVE
