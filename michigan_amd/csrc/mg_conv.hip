@@ -15,7 +15,9 @@
 // pipe).  bf16 uses v_mfma_f32_32x32x16_bf16, f32 uses v_mfma_f32_32x32x2_f32
 // (exact fp32 fma chain) -- same tiling, same LDS image (64 B of K per row).
 #include "mg_common.h"
+#include <type_traits>
 
+int g_mg_conv_bigtiles = 1;      // allow the 128x256 / 256x256 tiles (mg_set_option(1, v))
 int g_mg_conv_pipeline = 1;      // 0 = register-staged double buffer, 1 = LDS-DMA 3-stage ring (mg_set_option(0, v))
 
 namespace {
@@ -93,6 +95,12 @@ __device__ __forceinline__ void conv_compute(const unsigned char* As, const unsi
     }
 }
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
 template <typename T, int MT, int NT, int EPI>
 __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT][NT], int m0, int q0,
                                               int wm, int wn, int l31, int hi)
@@ -100,22 +108,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT
     const int HWj = d.Hj * d.Wj;
     // ---- epilogue -----------------------------------------------------------
     T* __restrict__ Out = reinterpret_cast<T*>(d.out);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    // compile-time tile indices (static_for): runtime-indexed accumulator arrays would be demoted to scratch
+    static_for<0, NT>([&](auto nt_) {
+        constexpr int nt = decltype(nt_)::value;
         const int q = q0 + wn * NT * 32 + nt * 32 + l31;
-        if (q >= d.ngemm) continue;
+        if (q >= d.ngemm) return;
         const int n = q / HWj, r = q - n * HWj;
         const int jy = r / d.Wj, jx = r - jy * d.Wj;
         const size_t opix = (size_t)((n * d.Hout + jy * d.osy + d.ooy) * d.Wout + jx * d.osx + d.oox);
 
         if constexpr (EPI == MG_EPI_PLAIN) {
             const T* __restrict__ Res = reinterpret_cast<const T*>(d.resid);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
+            static_for<0, MT * 4>([&](auto mr_) {
+                {
+                    constexpr int mt = decltype(mr_)::value / 4, rq = decltype(mr_)::value % 4;
                     const int co = m0 + wm * MT * 32 + mt * 32 + rq * 8 + hi * 4;
-                    if (co >= d.Cout) continue;
+                    if (co >= d.Cout) return;
                     f32x4_t v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][rq * 4 + j];
@@ -142,17 +150,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT
                         }
                     }
                 }
-            }
+            });
         } else {
             // SPADE: acc[0] = gamma rows, acc[1] = beta rows of the same 32 output channels.
             const T* __restrict__ X = reinterpret_cast<const T*>(d.x);
             T* __restrict__ G1 = reinterpret_cast<T*>(d.gamma_out);
             const int grow = m0 + wm * 64;              // first GEMM row of this wave's [gamma|beta] block
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
+            static_for<0, 4>([&](auto rq_) {
+                constexpr int rq = decltype(rq_)::value;
                 const int sub = rq * 8 + hi * 4;
                 const int oc = (grow >> 1) + sub;
-                if (oc >= d.Cout) continue;
+                if (oc >= d.Cout) return;
                 f32x4_t g, bt;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -180,9 +188,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT
                         }
                     }
                 }
-            }
+            });
         }
-    }
+    });
 }
 
 template <typename T, int WM, int WN, int MT, int NT, int EPI, bool PACK>
@@ -334,18 +342,25 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// Tile geometries: WM x WN waves (4 or 8 per workgroup), each wave MT x NT MFMA 32x32 tiles.
+//   (2,2,2,2) 128co x 128pix   (1,4,2,2) 64 x 256   (2,2,2,4) 128 x 256   (4,2,2,4) 256 x 256 (8 waves)
+// The operand stream comes out of L2 at ~64 B/clk/CU and everything in flight must sit in LDS, so at a
+// fixed LDS budget the only way to feed the matrix pipe faster is more FLOP per staged byte: the
+// 256x256 tile needs half the bytes per FLOP of the 128x128 one.
 template <typename T, int WM, int WN, int MT, int NT, int EPI, bool PACK>
-__global__ __launch_bounds__(NTHR) void conv_taps_glds_kernel(const ConvK d)
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && MT * NT >= 8) ? 2 : 1) void conv_taps_glds_kernel(const ConvK d)
 {
+    constexpr int NW = WM * WN;
     constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
     constexpr int EPP = 16 / (int)sizeof(T);
     constexpr int CH  = ROWB / (int)sizeof(T);
-    constexpr int A_IPS = TM / 64, B_IPS = TN / 64;          // 1 KiB wave-instructions per stage per wave
+    constexpr int A_IPS = TM / (16 * NW), B_IPS = TN / (16 * NW);   // 1 KiB wave-instructions per stage per wave
     constexpr int IPS = A_IPS + B_IPS;
-    constexpr int NS = 3;
     constexpr int STAGE = (TM + TN) * ROWB;
-    static_assert(WM * WN == 4 && TM % 64 == 0 && TN % 64 == 0, "tile must be whole 16-row blocks per wave");
-    static_assert(IPS == 4 || IPS == 5, "vmcnt immediates below assume 4 or 5 loads per stage");
+    constexpr int NS = (STAGE >= 32768) ? 4 : 3;                    // ring depth: NS-1 chunks in flight
+    static_assert((NW == 4 || NW == 8) && TM % (16 * NW) == 0 && TN % (16 * NW) == 0, "tile must be whole 16-row blocks per wave");
     static_assert(EPI == MG_EPI_PLAIN || MT == 2, "SPADE epilogue needs gamma/beta tile pair");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -377,7 +392,7 @@ __global__ __launch_bounds__(NTHR) void conv_taps_glds_kernel(const ConvK d)
     int b_n[B_IPS], b_y[B_IPS], b_x[B_IPS];
 #pragma unroll
     for (int j = 0; j < B_IPS; ++j) {
-        const int q = q0 + (wave + 4 * j) * 16 + lrow;
+        const int q = q0 + (wave + NW * j) * 16 + lrow;
         if (q < d.ngemm) {
             const int n = q / HWj, r = q - n * HWj;
             const int jy = r / d.Wj, jx = r - jy * d.Wj;
@@ -399,14 +414,14 @@ __global__ __launch_bounds__(NTHR) void conv_taps_glds_kernel(const ConvK d)
         const unsigned sbase = lds0 + stage * STAGE;
 #pragma unroll
         for (int j = 0; j < A_IPS; ++j) {
-            const int blk = wave + 4 * j;
+            const int blk = wave + NW * j;
             const void* src = g_mg_zeros;
             if (cv) src = Wt + ((size_t)(tap * d.CoutP + m0 + blk * 16 + lrow) * d.Cin + c);
             glds16(src, __builtin_amdgcn_readfirstlane(sbase + blk * 1024));
         }
 #pragma unroll
         for (int j = 0; j < B_IPS; ++j) {
-            const int blk = wave + 4 * j;
+            const int blk = wave + NW * j;
             const int iy = b_y[j] + dy, ix = b_x[j] + dx;
             const void* src = g_mg_zeros;
             if (cv && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win)
@@ -423,22 +438,22 @@ __global__ __launch_bounds__(NTHR) void conv_taps_glds_kernel(const ConvK d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    // prologue: chunks 0 and 1 in flight
+    // prologue: the first NS-1 chunks in flight
     int tap = 0, chunk = 0;                 // position of the NEXT chunk to issue
     auto advance = [&]() { if (++chunk == nchunk) { chunk = 0; ++tap; } };
-    issue(0, tap, chunk); advance();
-    if (nk > 1) { issue(1, tap, chunk); advance(); }
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) { issue(s, tap, chunk); advance(); }
 
-    int slot = 0, islot = 2;                // ring slot of chunk `it`, slot chunk it+2 goes to
+    int slot = 0, islot = NS - 1;           // ring slot of chunk `it`, slot chunk it+NS-1 goes to
     for (int it = 0; it < nk; ++it) {
-        if (it + 1 < nk) {
-            if constexpr (IPS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else                    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // chunk `it` must have landed; younger chunks (issued later by this wave) may stay in flight
+        const int younger = nk - 1 - it;
+        if (NS == 4 && younger >= 2) wait_vmcnt<2 * IPS>();
+        else if (younger >= 1)       wait_vmcnt<IPS>();
+        else                         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();       // every wave's part of chunk `it` has landed; chunk it-1 fully consumed
-        if (it + 2 < nk) { issue(islot, tap, chunk); advance(); }
+        if (it + NS - 1 < nk) { issue(islot, tap, chunk); advance(); }
         conv_compute<T, MT, NT>(smem + slot * STAGE + (wm * MT * 32) * ROWB,
                                 smem + slot * STAGE + (TM + wn * NT * 32) * ROWB, l31, hi, acc);
         slot = (slot == NS - 1) ? 0 : slot + 1;
@@ -473,30 +488,51 @@ int launch_conv_p(ConvK& k, hipStream_t st)
         return mg_fail(MG_ERR_ARG, "mg_conv_taps: CoutP=%d too small for Cout_gemm=%d (tile %d)", k.CoutP, k.Cout_gemm, TM);
     const long nblk = (long)k.tiles_m * tiles_n;
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_taps: bad grid %ld", nblk);
-    if constexpr (TM % 64 == 0) {
-        if (g_mg_conv_pipeline == 1) {
-            const size_t lds3 = 3 * (size_t)(TM + TN) * ROWB;
-            hipLaunchKernelGGL((conv_taps_glds_kernel<T, WM, WN, MT, NT, EPI, PACK>), dim3((unsigned)nblk), dim3(NTHR), lds3, st, k);
+    if constexpr (TM % (16 * WM * WN) == 0) {
+        if (g_mg_conv_pipeline == 1 || WM * WN != 4 || MT * NT > 4) {
+            const size_t stage = (size_t)(TM + TN) * ROWB;
+            const size_t ldsr = (stage >= 32768 ? 4 : 3) * stage;
+            auto kern = conv_taps_glds_kernel<T, WM, WN, MT, NT, EPI, PACK>;
+            if (ldsr > 65536) {
+                static bool attr_done = false;       // raise the dynamic-LDS cap once per instantiation
+                if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr); attr_done = true; }
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), ldsr, st, k);
             MG_CHECK_LAUNCH("mg_conv_taps(glds)");
             return MG_OK;
         }
     }
+    if constexpr (WM * WN != 4 || MT * NT > 4) return mg_fail(MG_ERR_UNSUPPORTED, "mg_conv_taps: large tiles need the LDS-DMA pipeline");
     const size_t lds = 2 * (size_t)(TM + TN) * ROWB;
-    hipLaunchKernelGGL((conv_taps_kernel<T, WM, WN, MT, NT, EPI, PACK>), dim3((unsigned)nblk), dim3(NTHR), lds, st, k);
-    MG_CHECK_LAUNCH("mg_conv_taps");
+    if constexpr (WM * WN == 4 && MT * NT <= 4) {
+        hipLaunchKernelGGL((conv_taps_kernel<T, WM, WN, MT, NT, EPI, PACK>), dim3((unsigned)nblk), dim3(NTHR), lds, st, k);
+        MG_CHECK_LAUNCH("mg_conv_taps");
+    }
     return MG_OK;
+}
+
+template <typename T, int EPI>
+int dispatch_tiles(ConvK& k, hipStream_t st)
+{
+    // Largest tile that still yields >= 1.5 workgroups per CU (256 CUs); big tiles halve the bytes
+    // staged per FLOP, small ones keep low-resolution layers from under-filling the chip.
+    auto wgs = [&](int tm, int tn) { return (long)((k.Cout_gemm + tm - 1) / tm) * ((k.ngemm + tn - 1) / tn); };
+    const bool big = g_mg_conv_pipeline == 1 && g_mg_conv_bigtiles;
+    // 256x256 (one 8-wave workgroup per CU) only pays when the K loop is long enough to amortise its
+    // exposed prologue/epilogue: measured +10..14 % at K >= 4608, -5..-13 % at K = 1152 (SPADE convs).
+    const int kchunks = k.ntaps * ((k.Cin * (int)sizeof(T) + ROWB - 1) / ROWB);
+    if (big && kchunks >= 64 && k.Cout_gemm >= 256 && (k.CoutP % 256) == 0 && wgs(256, 256) >= 384)
+        return launch_conv<T, 4, 2, 2, 4, EPI>(k, st);
+    if (k.Cout_gemm > 64) return launch_conv<T, 2, 2, 2, 2, EPI>(k, st);
+    if (EPI == MG_EPI_SPADE || k.Cout_gemm > 32) return launch_conv<T, 1, 4, 2, 2, EPI>(k, st);
+    if constexpr (EPI == MG_EPI_PLAIN) return launch_conv<T, 1, 4, 1, 2, EPI>(k, st);
+    return MG_ERR_UNSUPPORTED;
 }
 
 template <typename T>
 int dispatch_conv(ConvK& k, int epilogue, hipStream_t st)
 {
-    if (epilogue == MG_EPI_SPADE) {
-        if (k.Cout_gemm >= 128) return launch_conv<T, 2, 2, 2, 2, MG_EPI_SPADE>(k, st);
-        return launch_conv<T, 1, 4, 2, 2, MG_EPI_SPADE>(k, st);
-    }
-    if (k.Cout_gemm > 64) return launch_conv<T, 2, 2, 2, 2, MG_EPI_PLAIN>(k, st);
-    if (k.Cout_gemm > 32) return launch_conv<T, 1, 4, 2, 2, MG_EPI_PLAIN>(k, st);
-    return launch_conv<T, 1, 4, 1, 2, MG_EPI_PLAIN>(k, st);
+    return epilogue == MG_EPI_SPADE ? dispatch_tiles<T, MG_EPI_SPADE>(k, st) : dispatch_tiles<T, MG_EPI_PLAIN>(k, st);
 }
 
 }  // namespace
@@ -539,5 +575,6 @@ extern "C" int mg_conv_taps(const mg_conv_desc* d, void* stream)
 extern "C" int mg_set_option(int32_t key, int32_t value)
 {
     if (key == 0 && (value == 0 || value == 1)) { g_mg_conv_pipeline = value; return MG_OK; }
+    if (key == 1 && (value == 0 || value == 1)) { g_mg_conv_bigtiles = value; return MG_OK; }
     return mg_fail(MG_ERR_ARG, "mg_set_option: unknown key/value %d/%d", key, value);
 }
