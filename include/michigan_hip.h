@@ -187,6 +187,12 @@ int mg_blend_fwd(const void* bg, const void* x, const float* hair, const float* 
 int mg_blend_bwd(const void* dy, const float* hair, const float* back, void* dbg, void* dx,
                  int32_t dtype, int64_t P, int32_t C, void* stream);
 
+/* Fused L1 loss  mean|a - b|  over two same-shaped activation tensors (feature matching
+ * loss.py:163-175 and the VGG taps loss.py:199-207): forward in one pass (partial = >= 1024 floats of
+ * workspace, out = 1 float); backward da = sign(a - b) * gscale[0] / numel (b is a constant). */
+int mg_l1_mean_fwd(const void* a, const void* b, int32_t dtype, int64_t numel, float* out, float* partial, void* stream);
+int mg_l1_mean_bwd(const void* a, const void* b, const float* gscale, int32_t dtype, int64_t numel, void* da, void* stream);
+
 /* Fused Adam over one flat fp32 parameter buffer (torch.optim.Adam semantics,
  * pix2pix_model.py:137-145: eps 1e-8, no weight decay, bias correction).
  * step is the 1-based step count. */

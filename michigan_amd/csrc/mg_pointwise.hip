@@ -209,6 +209,52 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+
+// ---- fused L1 loss (feature matching / VGG perceptual taps, loss.py:163-175,199-207) -------------
+// forward: mean |a - b| with ONE pass over both tensors (block partials -> fixed-order fp64 finish);
+// backward: da = sign(a - b) * (*gscale) / numel in the activation dtype, ONE pass.  The eager form
+// (float casts, sub, abs, mean and their autograd) is ~10 passes over each feature map.
+template <typename T>
+__global__ __launch_bounds__(NTHR) void l1_partial_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                          float* __restrict__ partial, int64_t nquads)
+{
+    __shared__ float red[NTHR / 64];
+    float s = 0.f;
+    GRID_STRIDE(i, nquads) {
+        const f32x4_t x = ET<T>::load4(a + i * 4), y = ET<T>::load4(b + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += fabsf(x[j] - y[j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { float t = 0.f; for (int w = 0; w < NTHR / 64; ++w) t += red[w]; partial[blockIdx.x] = t; }
+}
+__global__ void l1_final_kernel(const float* __restrict__ partial, int n, double inv_numel, float* __restrict__ out)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = (float)(red[0] * inv_numel);
+}
+template <typename T>
+__global__ void l1_bwd_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ gscale,
+                              float inv_numel, T* __restrict__ da, int64_t nquads)
+{
+    const float g = gscale[0] * inv_numel;
+    GRID_STRIDE(i, nquads) {
+        const f32x4_t x = ET<T>::load4(a + i * 4), y = ET<T>::load4(b + i * 4);
+        f32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float dlt = x[j] - y[j]; o[j] = dlt > 0.f ? g : (dlt < 0.f ? -g : 0.f); }
+        ET<T>::store4(da + i * 4, o);
+    }
+}
+
 // ---- probes -----------------------------------------------------------------
 __global__ void probe_mfma_kernel(float* out)
 {
@@ -391,5 +437,31 @@ extern "C" int mg_probe_tr16(const uint16_t* in, uint16_t* out, void* stream)
     MG_CHECK_ARG(in && out, "mg_probe_tr16: null pointer");
     hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), in, out);
     MG_CHECK_LAUNCH("mg_probe_tr16");
+    return MG_OK;
+}
+
+extern "C" int mg_l1_mean_fwd(const void* a, const void* b, int32_t dtype, int64_t numel, float* out, float* partial, void* stream)
+{
+    MG_CHECK_ARG(a && b && out && partial, "mg_l1_mean_fwd: null pointer");
+    MG_CHECK_ARG((dtype == MG_F32 || dtype == MG_BF16) && numel > 0 && (numel % 4) == 0, "mg_l1_mean_fwd: numel must be a positive multiple of 4");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t nq = numel / 4;
+    int grid = ew_grid(nq); if (grid > 1024) grid = 1024;
+    if (dtype == MG_BF16) hipLaunchKernelGGL(l1_partial_kernel<uint16_t>, dim3(grid), dim3(NTHR), 0, st, (const uint16_t*)a, (const uint16_t*)b, partial, nq);
+    else hipLaunchKernelGGL(l1_partial_kernel<float>, dim3(grid), dim3(NTHR), 0, st, (const float*)a, (const float*)b, partial, nq);
+    MG_CHECK_LAUNCH("mg_l1_mean_fwd");
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, st, (const float*)partial, grid, 1.0 / (double)numel, out);
+    MG_CHECK_LAUNCH("mg_l1_mean_fwd(final)");
+    return MG_OK;
+}
+extern "C" int mg_l1_mean_bwd(const void* a, const void* b, const float* gscale, int32_t dtype, int64_t numel, void* da, void* stream)
+{
+    MG_CHECK_ARG(a && b && gscale && da, "mg_l1_mean_bwd: null pointer");
+    MG_CHECK_ARG((dtype == MG_F32 || dtype == MG_BF16) && numel > 0 && (numel % 4) == 0, "mg_l1_mean_bwd: numel must be a positive multiple of 4");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t nq = numel / 4;
+    if (dtype == MG_BF16) hipLaunchKernelGGL(l1_bwd_kernel<uint16_t>, dim3(ew_grid(nq)), dim3(NTHR), 0, st, (const uint16_t*)a, (const uint16_t*)b, gscale, (float)(1.0 / (double)numel), (uint16_t*)da, nq);
+    else hipLaunchKernelGGL(l1_bwd_kernel<float>, dim3(ew_grid(nq)), dim3(NTHR), 0, st, (const float*)a, (const float*)b, gscale, (float)(1.0 / (double)numel), (float*)da, nq);
+    MG_CHECK_LAUNCH("mg_l1_mean_bwd");
     return MG_OK;
 }

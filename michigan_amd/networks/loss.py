@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from .architecture import VGG19
 
 
@@ -90,11 +91,11 @@ class GANFeatLoss(nn.Module):
         total = pred_fake[0][0].new_zeros(1, dtype=torch.float32)
         for i in range(num_d):
             for j in range(len(pred_fake[i]) - 1):
-                a, b = pred_fake[i][j].float(), pred_real[i][j].detach().float()
+                a, b = pred_fake[i][j], pred_real[i][j].detach()
                 if getattr(self.opt, "remove_background", False):
-                    val = self.L1_loss_mask(a, b, label.detach().float())
+                    val = self.L1_loss_mask(a.float(), b.float(), label.detach().float())
                 else:
-                    val = F.l1_loss(a, b)
+                    val = ops.l1_mean(a, b)
                 total = total + val * self.opt.lambda_feat / num_d
         return total
 
@@ -120,9 +121,8 @@ class VGGLoss(nn.Module):
         x_feats = self.vgg(x)
         loss = 0
         for w, a, b in zip(self.weights, x_feats, y_feats):
-            a, b = a.float(), b.detach().float()
             if getattr(self.opt, "remove_background", False):
-                loss = loss + w * self.L1_loss_mask(a, b, label.detach().float())
+                loss = loss + w * self.L1_loss_mask(a.float(), b.detach().float(), label.detach().float())
             else:
-                loss = loss + w * F.l1_loss(a, b)
+                loss = loss + w * ops.l1_mean(a, b)
         return loss

@@ -558,6 +558,46 @@ def blend(bg, x, hair_mask, back_mask):
     return _BlendFn.apply(bg, x, hair_mask, back_mask)
 
 
+class _L1MeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        if a.shape != b.shape or a.dtype != b.dtype:
+            raise ValueError("l1_mean: tensors must agree in shape and dtype")
+        n = a.numel()
+        out = torch.empty(1, dtype=torch.float32, device=a.device)
+        ws = torch.empty(1024, dtype=torch.float32, device=a.device)
+        C.backend().mg_l1_mean_fwd(_p(a), _p(b), _dt(a), n, _p(out), _p(ws), _stream(a))
+        ctx.save_for_backward(a, b)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.reshape(1).float().contiguous()
+        da = torch.empty_like(a)
+        C.backend().mg_l1_mean_bwd(_p(a), _p(b), _p(g), _dt(a), a.numel(), _p(da), _stream(a))
+        return da, None
+
+
+def _dense_view(t: torch.Tensor) -> torch.Tensor:
+    """A contiguous alias of t when t is an NCHW view of NHWC memory (what the networks return), else a copy."""
+    if t.dim() == 4:
+        v = t.permute(0, 2, 3, 1)
+        if v.is_contiguous():
+            return v
+    return t.contiguous()
+
+
+def l1_mean(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """mean |a - b| (fp32 scalar) with gradient to `a` only; one HIP pass forward, one backward."""
+    a, b = _dense_view(a), _dense_view(b.detach())
+    if a.dtype != b.dtype:
+        b = b.to(a.dtype)
+    if a.numel() % 4 or a.dtype not in (torch.float32, torch.bfloat16):
+        return F.l1_loss(a.float(), b.float())
+    return _L1MeanFn.apply(a, b)
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, *, lr, beta1, beta2, eps, step, grad_scale=1.0):
     """In-place fused Adam on flat fp32 buffers (torch.optim.Adam semantics)."""
     for t in (param, grad, exp_avg, exp_avg_sq):

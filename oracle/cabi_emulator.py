@@ -289,6 +289,22 @@ class EmulatorBackend:
             _view(dx, (P, C), td)[:] = (d * (1 - bm)).to(td)
         return 0
 
+    def mg_l1_mean_fwd(self, a, b, dtype, numel, out, partial, stream=None):
+        td = _TD[dtype]
+        av, bv = _view(a, (numel,), td).double(), _view(b, (numel,), td).double()
+        _view(out, (1,), torch.float32)[0] = float((av - bv).abs().mean())
+        return 0
+
+    def mg_l1_mean_bwd(self, a, b, gscale, dtype, numel, da, stream=None):
+        td = _TD[dtype]
+        av, bv = _view(a, (numel,), td).double(), _view(b, (numel,), td).double()
+        g = float(_view(gscale, (1,), torch.float32)[0]) / numel
+        _view(da, (numel,), td)[:] = (torch.sign(av - bv) * g).to(td)
+        return 0
+
+    def mg_set_option(self, key, value):
+        return 0
+
     def mg_adam_step(self, param, grad, m, v, numel, lr, b1, b2, eps, step, gscale, stream=None):
         p = _view(param, (numel,), torch.float32)
         g = _view(grad, (numel,), torch.float32) * gscale

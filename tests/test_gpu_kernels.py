@@ -284,3 +284,21 @@ def test_conv_matches_miopen_large_bf16():
     _close("conv vs torch gpu", y, ref, 2.0 ** -7)
     y2 = ops.conv2d(x * 2, w, None, padding=1).float()
     _close("linearity", y2, 2 * y, 2.0 ** -7)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_l1_mean_fused(dt):
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(12)
+    a = torch.randn(3, 37, 29, 64, generator=g).to(DT[dt]).requires_grad_()
+    b = torch.randn(3, 37, 29, 64, generator=g).to(DT[dt])
+
+    def fn(a, b):
+        loss = ops.l1_mean(a.permute(0, 3, 1, 2), b.permute(0, 3, 1, 2)) * 3.0
+        (ga,) = torch.autograd.grad(loss, a)
+        return loss.reshape(1), ga
+    (hip, _), (ref, _) = _both(fn, (a, b))
+    _close(f"l1 {dt} loss", hip[0], ref[0], 1e-5)
+    _close(f"l1 {dt} grad", hip[1], ref[1], TOL[dt])
+    want = torch.nn.functional.l1_loss(a.detach().float(), b.float()) * 3.0
+    _close(f"l1 {dt} vs torch", hip[0], want.reshape(1), 1e-5)
