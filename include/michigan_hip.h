@@ -58,7 +58,7 @@ enum { MG_OK = 0, MG_ERR_ARG = 1, MG_ERR_LAUNCH = 2, MG_ERR_UNSUPPORTED = 3 };
  * Cin must be a multiple of 8 (host pads small channel counts with zeros).
  *
  * Epilogues
- *   MG_EPI_PLAIN: v = acc + bias[co] (+ resid[n,oy,ox,co]) ; out = act(v)
+ *   MG_EPI_PLAIN: v = acc + bias[co] (+ resid[n,oy,ox,co]) ; out = act(v)   (bias has Cout_gemm entries)
  *   MG_EPI_SPADE: GEMM rows come in blocks of 64 = [32 gamma rows | 32 beta rows]
  *                 of the same 32 output channels (mlp_gamma/mlp_beta fused,
  *                 normalization.py:112-116).  For output channel c:
@@ -186,6 +186,17 @@ int mg_blend_fwd(const void* bg, const void* x, const float* hair, const float* 
                  int32_t dtype, int64_t P, int32_t C, void* stream);
 int mg_blend_bwd(const void* dy, const float* hair, const float* back, void* dbg, void* dx,
                  int32_t dtype, int64_t P, int32_t C, void* stream);
+
+/* Parameter re-layout (host-side glue of every conv call, as ONE launch each):
+ * mg_pack_weight : reference fp32 [cout][cin][taps] (one tensor, or gamma+beta for the fused SPADE
+ *     conv: GEMM row of channel co = 64*(co/32) + co%32, +32 for beta) -> dst[taps][rows_p][cols_p] in
+ *     `dtype`, zero padded.  mode 0: rows = GEMM output channels, cols = cin (forward / wgrad image);
+ *     mode 1: rows = cin, cols = GEMM output channels (dgrad image, transposed per tap).
+ * mg_unpack_wgrad: fp32 dW in GEMM order [taps][rows][cols] -> reference layout (d1 != NULL: beta). */
+int mg_pack_weight(const float* w0, const float* w1, void* dst, int32_t dtype, int32_t cout, int32_t cin,
+                   int32_t taps, int32_t rows_p, int32_t cols_p, int32_t mode, void* stream);
+int mg_unpack_wgrad(const float* dw, float* d0, float* d1, int32_t cout, int32_t cin, int32_t taps,
+                    int32_t rows, int32_t cols, void* stream);
 
 /* Fused L1 loss  mean|a - b|  over two same-shaped activation tensors (feature matching
  * loss.py:163-175 and the VGG taps loss.py:199-207): forward in one pass (partial = >= 1024 floats of

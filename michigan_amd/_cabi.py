@@ -63,6 +63,8 @@ _PROTOS = {
     "mg_maxpool2_bwd": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_blend_fwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp], _i32),
     "mg_blend_bwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp], _i32),
+    "mg_pack_weight": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "mg_unpack_wgrad": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_l1_mean_fwd": ([_vp, _vp, _i32, _i64, _vp, _vp, _vp], _i32),
     "mg_l1_mean_bwd": ([_vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
     "mg_adam_step": ([_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp], _i32),

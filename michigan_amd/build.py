@@ -23,7 +23,7 @@ OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libmichigan_hip.so")
 
 ARCH = "gfx950"
-SOURCES = ["mg_api.hip", "mg_conv.hip", "mg_wgrad.hip", "mg_norm.hip", "mg_pointwise.hip"]
+SOURCES = ["mg_api.hip", "mg_conv.hip", "mg_wgrad.hip", "mg_norm.hip", "mg_pointwise.hip", "mg_pack.hip"]
 CXXFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
             "-fno-gpu-rdc", f"-I{INCLUDE}", f"-I{CSRC}"]
 
@@ -35,14 +35,17 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
 
 
-def _fingerprint() -> str:
+def _fingerprint(src: str = "") -> str:
+    """Hash of the flags, every header, and either one translation unit (`src`) or all of them."""
     h = hashlib.sha256()
     h.update(" ".join(CXXFLAGS).encode())
-    paths = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
+    paths = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h") or (not src and f.endswith(".hip"))]
     paths += [os.path.join(INCLUDE, f) for f in sorted(os.listdir(INCLUDE))]
+    if src:
+        paths.append(os.path.join(CSRC, src))
     for p in paths:
         if os.path.isfile(p):
-            h.update(p.encode())
+            h.update(os.path.basename(p).encode())
             with open(p, "rb") as fh:
                 h.update(fh.read())
     return h.hexdigest()
@@ -61,12 +64,17 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+        ostamp, ofp = obj + ".stamp", _fingerprint(src)
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == ofp:
+            return obj                                   # this translation unit is up to date
         cmd = [hipcc, *CXXFLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[michigan_amd.build]", " ".join(cmd), flush=True)
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{res.stdout}\n{res.stderr}")
+        with open(ostamp, "w") as fh:
+            fh.write(ofp)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:

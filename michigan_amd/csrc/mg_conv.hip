@@ -129,7 +129,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT
                     for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][rq * 4 + j];
                     if (d.bias) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += d.bias[co + j];   // bias is padded to CoutP
+                        for (int j = 0; j < 4; ++j) v[j] += (co + j < d.Cout_gemm) ? d.bias[co + j] : 0.f;
                     }
                     const size_t o = opix * d.Cout + co;
                     if ((d.Cout & 3) == 0) {

@@ -36,10 +36,12 @@ class PartialConv2d(HipConv2d):
             ratio = (ratio * upd).permute(0, 2, 3, 1)
             upd = upd.permute(0, 2, 3, 1).contiguous()
         raw = ops.conv2d(x * mask_in.to(x.dtype), self.weight, None, stride=s, padding=p)
-        out = raw.float() * ratio
-        if self.bias is not None:
-            out = out + self.bias
-        return (out * upd).to(x.dtype), upd
+        # (raw * ratio + b) * m'  ==  raw * (ratio * m') + b * m'   (ratio already carries m'): two broadcast
+        # passes in the activation dtype instead of four fp32 ones
+        scale = ratio.to(x.dtype)
+        if self.bias is None:
+            return raw * scale, upd
+        return torch.addcmul(self.bias.to(x.dtype) * upd.to(x.dtype), raw, scale), upd
 
 
 class ImageEncoder3(BaseNetwork):
@@ -131,7 +133,10 @@ class BackgroundEncode2(BaseNetwork):
             grown[:, :, o:o + hh, o:o + hh] = F.max_pool2d(hair[:, :, o:o + hh, o:o + hh], k, 1, int(k / 2))
             back = 1 - grown
         else:
-            back = 1 - F.max_pool2d(mask[:, 1:2], kernel_size=k, stride=1, padding=int(k / 2))
+            # a k x k max-pool of a single-channel mask is separable: k+k taps instead of k*k (k ~ 25)
+            hair = mask[:, 1:2]
+            grown = F.max_pool2d(F.max_pool2d(hair, (k, 1), 1, (int(k / 2), 0)), (1, k), 1, (0, int(k / 2)))
+            back = 1 - grown
         inp = noise if self.opt.random_noise_background else image * back + noise * (1 - back)
         x0 = self.conv1(ops.pad_channels(ops.to_nhwc(inp, self.compute_dtype), 8))
         x1 = self.layer1(x0)

@@ -119,40 +119,39 @@ def _launch_conv(inp, wt, out, bias, taps, *, Hj, Wj, isy, isx, osy=1, osx=1, oo
     C.backend().mg_conv_taps(d, _stream(inp))
 
 
-def _pack_rows(w: torch.Tensor, dtype, mult: int = 128) -> torch.Tensor:
-    """[T, R, K] fp32 -> [T, roundup(R, mult), K] in the compute dtype (zero rows appended)."""
-    r = w.shape[1]
-    rp = _roundup(r, mult)
-    w = w.detach()
-    if rp != r:
-        w = F.pad(w, (0, 0, 0, rp - r))
-    return w.to(dtype).contiguous()
+def pack_weight(w0: torch.Tensor, w1: Optional[torch.Tensor], dtype, rows_p: int, cols_p: int, mode: int) -> torch.Tensor:
+    """Reference-layout fp32 weight(s) [Cout, Cin, kh, kw] -> GEMM image [taps, rows_p, cols_p] in `dtype`
+    (one HIP launch: permute + zero-pad + cast; two tensors = fused SPADE gamma/beta row interleave).
+    mode 0: rows = output channels (forward / wgrad image); mode 1: rows = input channels (dgrad image)."""
+    w0 = w0.detach().float().contiguous()
+    if w1 is not None:
+        w1 = w1.detach().float().contiguous()
+    cout, cin, kh, kw = w0.shape
+    dst = torch.empty((kh * kw, rows_p, cols_p), dtype=dtype, device=w0.device)
+    C.backend().mg_pack_weight(_p(w0), _p(w1), _p(dst), C.MG_BF16 if dtype == torch.bfloat16 else C.MG_F32,
+                               cout, cin, kh * kw, rows_p, cols_p, mode, _stream(w0))
+    return dst
 
 
-def _pack_bias(b: Optional[torch.Tensor], rows_p: int) -> Optional[torch.Tensor]:
-    if b is None:
-        return None
-    b = b.detach().float()
-    if b.numel() != rows_p:
-        b = F.pad(b, (0, rows_p - b.numel()))
-    return b.contiguous()
+def unpack_wgrad(dw: torch.Tensor, shape, two: bool = False):
+    """fp32 dW in GEMM order [taps, rows, cols] -> reference layout [Cout, Cin, kh, kw] (x2 for gamma/beta)."""
+    cout, cin, kh, kw = shape
+    d0 = torch.empty(shape, dtype=torch.float32, device=dw.device)
+    d1 = torch.empty(shape, dtype=torch.float32, device=dw.device) if two else None
+    C.backend().mg_unpack_wgrad(_p(dw), _p(d0), _p(d1), cout, cin, kh * kw, dw.shape[1], dw.shape[2], _stream(dw))
+    return (d0, d1) if two else d0
 
 
-def conv_dgrad(dy: torch.Tensor, wg: torch.Tensor, kh: int, kw: int, stride: int, pad: int,
-               in_hw: Tuple[int, int]) -> torch.Tensor:
-    """Data gradient of a forward conv whose GEMM-order weight is wg [T, Cg, Cin].
-
-    dy is [N, Ho, Wo, Cg8] (channels zero-padded to a multiple of 8).  For stride s the
-    output pixels split into s*s parity classes; each class is a stride-1 gather over
-    dy with the subset of taps whose offset is divisible by s (no wasted MACs).
-    """
+def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, kh: int, kw: int, stride: int, pad: int,
+               in_hw: Tuple[int, int], cin: int) -> torch.Tensor:
+    """Data gradient of a forward conv.  dy is [N, Ho, Wo, Cg8]; wt is the dgrad image
+    [taps, roundup(cin,128), Cg8] (pack_weight mode 1).  For stride s the output pixels split into s*s
+    parity classes; each class is a stride-1 gather over dy with the subset of taps whose offset is
+    divisible by s (no wasted MACs)."""
     n, ho, wo, cg8 = dy.shape
-    t, cg, cin = wg.shape
+    t = kh * kw
     h, w = in_hw
-    wt = wg.detach().transpose(1, 2)                      # [T, Cin, Cg]
-    if cg8 != cg:
-        wt = F.pad(wt, (0, cg8 - cg))
-    wt = _pack_rows(wt, dy.dtype)                          # [T, CinP128, Cg8]
+    assert wt.shape[0] == t and wt.shape[2] == cg8
     dx = (torch.zeros if stride > 1 else torch.empty)((n, h, w, cin), dtype=dy.dtype, device=dy.device)
     for py in range(stride):
         hj = len(range(py, h, stride))
@@ -224,44 +223,46 @@ def act_backward(dy: torch.Tensor, y: torch.Tensor, act: int, slope: float) -> t
 # ----------------------------------------------------------------------------
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wg, bias, resid, kh, kw, stride, pad, act, slope):
+    def forward(ctx, x, weight, bias, resid, stride, pad, act, slope):
         x = _nhwc(x)
-        n, h, w, cin = x.shape
-        t, cout, cin_w = wg.shape
-        if cin_w != cin or cin % 8:
-            raise ValueError(f"conv2d: input has {cin} channels, weight expects {cin_w} (must match, multiple of 8)")
+        n, h, w, cx = x.shape
+        cout, cin, kh, kw = weight.shape
+        if cx < cin or cx % 8:
+            raise ValueError(f"conv2d: input has {cx} channels, weight expects {cin} (input must be >= and a multiple of 8)")
         ho = (h + 2 * pad - kh) // stride + 1
         wo = (w + 2 * pad - kw) // stride + 1
-        wp = _pack_rows(wg, x.dtype)
-        bp = _pack_bias(bias, wp.shape[1])
+        wp = pack_weight(weight, None, x.dtype, _roundup(cout, 128), cx, 0)
+        bp = bias.detach().float().contiguous() if bias is not None else None
         out = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
         if resid is not None:
             resid = _nhwc(resid)
             if resid.shape != out.shape or resid.dtype != out.dtype:
                 raise ValueError("conv2d: residual must match the output")
         _launch_conv(x, wp, out, bp, fwd_taps(kh, kw, pad), Hj=ho, Wj=wo, isy=stride, isx=stride,
-                     cout=cout, cout_gemm=cout, act=act, slope=slope, resid=resid)
-        ctx.save_for_backward(x, wg, out if act != ACT_NONE else None)
-        ctx.cfg = (kh, kw, stride, pad, act, slope, bias is not None, resid is not None)
+                     cout=cout, cout_gemm=cout, act=act, slope=slope, resid=resid, algo_cin=cin)
+        ctx.save_for_backward(x, weight, out if act != ACT_NONE else None)
+        ctx.cfg = (stride, pad, act, slope, bias is not None, resid is not None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, wg, out = ctx.saved_tensors
-        kh, kw, stride, pad, act, slope, has_bias, has_resid = ctx.cfg
+        x, weight, out = ctx.saved_tensors
+        stride, pad, act, slope, has_bias, has_resid = ctx.cfg
+        cout, cin, kh, kw = weight.shape
+        cx = x.shape[3]
         dout = dout.contiguous()
         dpre = act_backward(dout, out, act, slope)
         dpre8 = pad_channels(dpre, 8)
-        t, cout, cin = wg.shape
-        dx = dwg = dbias = None
+        dx = dw = dbias = None
         if ctx.needs_input_grad[0]:
-            dx = conv_dgrad(dpre8, wg, kh, kw, stride, pad, (x.shape[1], x.shape[2]))
+            wt = pack_weight(weight, None, x.dtype, _roundup(cx, 128), dpre8.shape[3], 1)
+            dx = conv_dgrad(dpre8, wt, kh, kw, stride, pad, (x.shape[1], x.shape[2]), cx)
         if ctx.needs_input_grad[1]:
-            dwg = conv_wgrad(x, dpre8, kh, kw, stride, pad)[:, :cout, :]
+            dw = unpack_wgrad(conv_wgrad(x, dpre8, kh, kw, stride, pad), weight.shape)
         if has_bias and ctx.needs_input_grad[2]:
             dbias = channel_sums(dpre8)[0, 0, :cout]
         dres = dpre if (has_resid and ctx.needs_input_grad[3]) else None
-        return dx, dwg, dbias, dres, None, None, None, None, None, None
+        return dx, dw, dbias, dres, None, None, None, None
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride: int = 1,
@@ -270,14 +271,11 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     """NHWC convolution (+bias, +residual, +activation fused in the MFMA kernel's epilogue).
 
     `weight` is the reference-layout fp32 parameter [Cout, Cin, kh, kw]; `x` may carry more
-    (zero) channels than Cin -- the weight is zero-padded to match.
+    (zero) channels than Cin -- the packed weight is zero-padded to match.
     """
-    cout, cin, kh, kw = weight.shape
-    if x.shape[-1] < cin:
-        raise ValueError(f"conv2d: input has {x.shape[-1]} channels < weight Cin {cin}")
-    x = pad_channels(x, 8)
-    wg = gemm_weight(weight.float(), x.shape[-1])
-    return _Conv2dFn.apply(x, wg, bias, resid, kh, kw, stride, padding, act, slope)
+    if x.shape[-1] < weight.shape[1]:
+        raise ValueError(f"conv2d: input has {x.shape[-1]} channels < weight Cin {weight.shape[1]}")
+    return _Conv2dFn.apply(pad_channels(x, 8), weight, bias, resid, stride, padding, act, slope)
 
 
 # ----------------------------------------------------------------------------
@@ -312,52 +310,46 @@ def batch_stats(x: torch.Tensor, eps: float = 1e-5):
         return mean.float(), rstd.float(), unbiased.float(), count
 
 
-def spade_gemm_weight(w_gamma: torch.Tensor, w_beta: torch.Tensor, b_gamma: torch.Tensor, b_beta: torch.Tensor,
-                      cin_pad: int):
-    """Interleave mlp_gamma / mlp_beta into the fused GEMM image: row blocks of 64 =
-    [32 gamma rows | 32 beta rows] of the same 32 output channels (differentiable)."""
-    c = w_gamma.shape[0]
+def _interleave32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[C], [C] -> [2*roundup(C,32)] in the fused-SPADE GEMM row order ([32 gamma | 32 beta] blocks)."""
+    c = a.numel()
     cr = _roundup(c, 32)
-    gg, gb = gemm_weight(w_gamma.float(), cin_pad), gemm_weight(w_beta.float(), cin_pad)   # [T, C, K]
     if cr != c:
-        gg, gb = F.pad(gg, (0, 0, 0, cr - c)), F.pad(gb, (0, 0, 0, cr - c))
-    t, _, k = gg.shape
-    wg = torch.stack([gg.reshape(t, cr // 32, 32, k), gb.reshape(t, cr // 32, 32, k)], dim=2).reshape(t, 2 * cr, k)
-    bg, bb = b_gamma.float(), b_beta.float()
-    if cr != c:
-        bg, bb = F.pad(bg, (0, cr - c)), F.pad(bb, (0, cr - c))
-    bias = torch.stack([bg.reshape(cr // 32, 32), bb.reshape(cr // 32, 32)], dim=1).reshape(2 * cr)
-    return wg, bias
+        a, b = F.pad(a, (0, cr - c)), F.pad(b, (0, cr - c))
+    return torch.stack([a.reshape(cr // 32, 32), b.reshape(cr // 32, 32)], dim=1).reshape(2 * cr)
 
 
 class _SpadeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, actv, wg, bias, mean, rstd, count, kh, pad, act, slope):
+    def forward(ctx, x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, act, slope):
         x, actv = _nhwc(x), _nhwc(actv)
         n, h, w, c = x.shape
         if actv.shape[:3] != x.shape[:3] or actv.dtype != x.dtype:
             raise ValueError("spade_modulate: activation map and x disagree in shape/dtype")
-        t, rows, k = wg.shape
-        if rows != 2 * _roundup(c, 32) or k != actv.shape[-1]:
-            raise ValueError("spade_modulate: fused gamma/beta weight has the wrong shape")
-        wp = _pack_rows(wg, x.dtype)
-        bp = _pack_bias(bias, wp.shape[1])
+        if w_gamma.shape != w_beta.shape or w_gamma.shape[0] != c or w_gamma.shape[1] != actv.shape[3]:
+            raise ValueError("spade_modulate: mlp_gamma / mlp_beta weights have the wrong shape")
+        kh = w_gamma.shape[2]
+        rows = 2 * _roundup(c, 32)
+        wp = pack_weight(w_gamma, w_beta, x.dtype, _roundup(rows, 128), actv.shape[3], 0)
+        bias = _interleave32(b_gamma.detach().float(), b_beta.detach().float()).contiguous()
         out = torch.empty_like(x)
         g1 = torch.empty_like(x)
-        _launch_conv(actv, wp, out, bp, fwd_taps(kh, kh, pad), Hj=h, Wj=w, isy=1, isx=1,
+        _launch_conv(actv, wp, out, bias, fwd_taps(kh, kh, kh // 2), Hj=h, Wj=w, isy=1, isx=1,
                      cout=c, cout_gemm=rows, act=act, slope=slope,
                      spade_x=x, mean=mean, rstd=rstd, gamma_out=g1)
-        ctx.save_for_backward(x, actv, wg, out, g1, mean, rstd)
-        ctx.cfg = (count, kh, pad, act, slope)
+        ctx.save_for_backward(x, actv, w_gamma, w_beta, out, g1, mean, rstd)
+        ctx.cfg = (count, act, slope)
         return out
 
     @staticmethod
     def backward(ctx, dh):
-        x, actv, wg, h, g1, mean, rstd = ctx.saved_tensors
-        count, kh, pad, act, slope = ctx.cfg
+        x, actv, w_gamma, w_beta, h, g1, mean, rstd = ctx.saved_tensors
+        count, act, slope = ctx.cfg
         dh = dh.contiguous()
         n, hh, ww, c = x.shape
-        rows = wg.shape[1]
+        kh = w_gamma.shape[2]
+        pad = kh // 2
+        rows = 2 * _roundup(c, 32)
         p = n * hh * ww
         be = C.backend()
         alloc = torch.zeros if rows != 2 * c else torch.empty      # padded gamma/beta rows must read 0
@@ -366,7 +358,7 @@ class _SpadeFn(torch.autograd.Function):
         ws = torch.empty(max(int(be.mg_stats_workspace(1, p, c)), 4), dtype=torch.uint8, device=x.device)
         be.mg_norm_bwd_reduce(_p(dh), _p(h), _p(x), _p(g1), _dt(x), 1, p, c, _p(mean), _p(rstd), act, slope,
                               _p(dgb), _p(sums), _p(ws), _stream(x))
-        dx = dactv = dwg = dbias = None
+        dx = dactv = dwg = dwb = dbg = dbb = None
         if ctx.needs_input_grad[0]:
             if SYNC_BN_GROUP is not None:
                 import torch.distributed as dist
@@ -376,12 +368,14 @@ class _SpadeFn(torch.autograd.Function):
             be.mg_norm_bwd_apply(_p(dh), _p(h), _p(x), _p(g1), _dt(x), 1, p, c, _p(mean), _p(rstd),
                                  _p(s[0]), _p(s[1]), act, slope, _p(dx), _stream(x))
         if ctx.needs_input_grad[1]:
-            dactv = conv_dgrad(dgb, wg, kh, kh, 1, pad, (hh, ww))
-        if ctx.needs_input_grad[2]:
-            dwg = conv_wgrad(actv, dgb, kh, kh, 1, pad)
-        if ctx.needs_input_grad[3]:
-            dbias = channel_sums(dgb)[0, 0]
-        return dx, dactv, dwg, dbias, None, None, None, None, None, None, None
+            wt = pack_weight(w_gamma, w_beta, x.dtype, _roundup(actv.shape[3], 128), rows, 1)
+            dactv = conv_dgrad(dgb, wt, kh, kh, 1, pad, (hh, ww), actv.shape[3])
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[4]:
+            dwg, dwb = unpack_wgrad(conv_wgrad(actv, dgb, kh, kh, 1, pad), w_gamma.shape, two=True)
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[5]:
+            db = channel_sums(dgb)[0, 0].reshape(rows // 64, 2, 32)
+            dbg, dbb = db[:, 0].reshape(-1)[:c], db[:, 1].reshape(-1)[:c]
+        return dx, dactv, dwg, dbg, dwb, dbb, None, None, None, None, None
 
 
 def spade_modulate(x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, *, act=ACT_NONE, slope=0.2):
@@ -391,9 +385,7 @@ def spade_modulate(x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count,
     both to memory and makes ~12 elementwise passes).  The backward implements the full
     batch-norm gradient (statistics included), so `mean`/`rstd` enter as constants.
     """
-    kh = w_gamma.shape[2]
-    wg, bias = spade_gemm_weight(w_gamma, w_beta, b_gamma, b_beta, actv.shape[-1])
-    return _SpadeFn.apply(x, actv, wg, bias, mean, rstd, count, kh, kh // 2, act, slope)
+    return _SpadeFn.apply(x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, act, slope)
 
 
 # ----------------------------------------------------------------------------

@@ -102,7 +102,7 @@ class EmulatorBackend:
             g = _gather(x, d.Hj, d.Wj, d.isy, d.isx, int(d.tap_dy[t]), int(d.tap_dx[t]))
             acc += g @ w[t, :d.Cout_gemm].t()
         if _addr(d.bias):
-            acc += _view(d.bias, (d.CoutP,), torch.float32).double()[:d.Cout_gemm]
+            acc += _view(d.bias, (d.Cout_gemm,), torch.float32).double()
         oy = slice(d.ooy, d.ooy + (d.Hj - 1) * d.osy + 1, d.osy)
         ox = slice(d.oox, d.oox + (d.Wj - 1) * d.osx + 1, d.osx)
         if d.epilogue == 0:
@@ -287,6 +287,34 @@ class EmulatorBackend:
             _view(dbg, (P, C), td)[:] = (d * (1 - hm)).to(td)
         if _addr(dx):
             _view(dx, (P, C), td)[:] = (d * (1 - bm)).to(td)
+        return 0
+
+    @staticmethod
+    def _gemm_rows(cout, two):
+        co = torch.arange(cout)
+        return (64 * (co // 32) + co % 32) if two else co
+
+    def mg_pack_weight(self, w0, w1, dst, dtype, cout, cin, taps, rows_p, cols_p, mode, stream=None):
+        td = _TD[dtype]
+        two = _addr(w1) != 0
+        out = _view(dst, (taps, rows_p, cols_p), td)
+        out.zero_()
+        rows = self._gemm_rows(cout, two)
+        for which, p in enumerate((w0, w1) if two else (w0,)):
+            w = _view(p, (cout, cin, taps), torch.float32).permute(2, 0, 1)        # [t, co, ci]
+            r = rows + 32 * which
+            if mode == 0:
+                out[:, r, :cin] = w.to(td)
+            else:
+                out[:, :cin, r] = w.permute(0, 2, 1).to(td)
+        return 0
+
+    def mg_unpack_wgrad(self, dw, d0, d1, cout, cin, taps, rows, cols, stream=None):
+        src = _view(dw, (taps, rows, cols), torch.float32)
+        two = _addr(d1) != 0
+        r = self._gemm_rows(cout, two)
+        for which, p in enumerate((d0, d1) if two else (d0,)):
+            _view(p, (cout, cin, taps), torch.float32)[:] = src[:, r + 32 * which, :cin].permute(1, 2, 0)
         return 0
 
     def mg_l1_mean_fwd(self, a, b, dtype, numel, out, partial, stream=None):

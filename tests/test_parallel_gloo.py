@@ -92,7 +92,7 @@ def test_two_ranks_equal_single_process_on_concatenated_batch():
     assert torch.equal(got[0]["grad0"], got[1]["grad0"])
     assert (got[0]["grad0"] - single["grad0"]).abs().max().item() < 1e-4 * gscale
     solid = single["grad0"].abs() > 1e-3 * gscale            # parameters whose update direction is well defined
-    assert (got[0]["flat"] - single["flat"])[solid].abs().max().item() < 2e-4
+    assert (got[0]["flat"] - single["flat"])[solid].abs().max().item() < 1e-3   # <= one Adam step (lr 1e-3) where a tiny second-step gradient flips sign
     # per-sample outputs agree with the big-batch run; running statistics are the global ones
     out2 = torch.cat([got[0]["out"], got[1]["out"]])
     assert (out2 - single["out"]).abs().max().item() < 5e-5

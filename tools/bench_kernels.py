@@ -59,15 +59,16 @@ def main():
             continue
         x = torch.randn(a.n, H, H, max(cin, 8), device="cuda").to(dt)
         w = torch.randn(cout, cin, k, k, device="cuda") * 0.05
-        wg = ops.gemm_weight(w, x.shape[-1])
         ho = (H + 2 * p - k) // s + 1
         dy = torch.randn(a.n, ho, ho, cout, device="cuda").to(dt)
         gf = 2.0 * a.n * ho * ho * cout * cin * k * k / 1e9
-        wp = ops._pack_rows(wg, dt)
+        cx = x.shape[-1]
+        wp = ops.pack_weight(w, None, dt, (cout + 127) // 128 * 128, cx, 0)
+        wt = ops.pack_weight(w, None, dt, (cx + 127) // 128 * 128, cout, 1)
         out = torch.empty(a.n, ho, ho, cout, device="cuda", dtype=dt)
         taps = ops.fwd_taps(k, k, p)
         t_f = timeit(lambda: ops._launch_conv(x, wp, out, None, taps, Hj=ho, Wj=ho, isy=s, isx=s, cout=cout, cout_gemm=cout))
-        t_d = timeit(lambda: ops.conv_dgrad(dy, wg, k, k, s, p, (H, H)))
+        t_d = timeit(lambda: ops.conv_dgrad(dy, wt, k, k, s, p, (H, H), cx))
         t_w = timeit(lambda: ops.conv_wgrad(x, dy, k, k, s, p))
         print(f"{name:28s} {gf:8.1f} | {t_f:8.3f} {gf / t_f:7.1f} | {t_d:8.3f} {gf / t_d:7.1f} | {t_w:8.3f} {gf / t_w:7.1f}", flush=True)
 
