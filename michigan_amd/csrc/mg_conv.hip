@@ -329,7 +329,8 @@ __global__ __launch_bounds__(NTHR) void conv_taps_kernel(const ConvK d)
 // schedule per K chunk is:  wait(vmcnt = one stage of this wave's loads still in flight) -> s_barrier
 // -> issue chunk it+2 into the slot consumed at it-1 -> MFMAs on chunk it.
 // ---------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(64))) unsigned char g_mg_zeros[64];
+// zero source for out-of-image taps / tail rows: long enough to be walked chunk by chunk (<= 8 KiB of K per tap: Cin <= 4096 bf16 / 2048 f32)
+__device__ __attribute__((aligned(64))) unsigned char g_mg_zeros[8192 + 64];
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
 {
@@ -405,28 +406,51 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && MT * NT >= 8) ? 2 : 
     const int ptap = PACK ? (piece * EPP) / d.Cin : 0;
     const int pch  = PACK ? (piece * EPP) % d.Cin : 0;
 
-    auto issue = [&](int stage, int tap, int chunk) {
-        if constexpr (PACK) { tap = tap * d.tpc + ptap; }
+    // Source pointers are kept per row and WALKED: inside a tap the next chunk is +64 bytes for every row
+    // (valid or not -- invalid rows walk the zero block), so the steady-state cost of a load is one 64-bit
+    // add; tap decode, bounds checks and base addresses are redone only at tap boundaries (or every
+    // iteration in PACK mode, where each chunk holds several taps).  The tap table sits in one VGPR
+    // (lane t = tap t) and is read with v_readlane instead of a kernarg load + s_waitcnt per iteration.
+    const int tapv = d.tap[lane];
+    const unsigned char* pa[A_IPS];
+    const unsigned char* pb[B_IPS];
+    const bool tail_ok = (d.Cin % CH) == 0;      // otherwise the last chunk of a tap needs a channel check
+
+    auto set_tap = [&](int tap, int chunk) {
+        int ltap = tap;
+        if constexpr (PACK) ltap = tap * d.tpc + ptap;
         const int c = PACK ? pch : chunk * CH + piece * EPP;
-        const bool cv = PACK ? (tap < d.ntaps) : (c < d.Cin);
-        const int tp = d.tap[cv || !PACK ? tap : 0];
+        const bool cv = PACK ? (ltap < d.ntaps) : (c < d.Cin);
+        int tp;
+        if constexpr (PACK) tp = d.tap[cv ? ltap : 0];
+        else                tp = __builtin_amdgcn_readlane(tapv, tap);
         const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
-        const unsigned sbase = lds0 + stage * STAGE;
 #pragma unroll
         for (int j = 0; j < A_IPS; ++j) {
             const int blk = wave + NW * j;
-            const void* src = g_mg_zeros;
-            if (cv) src = Wt + ((size_t)(tap * d.CoutP + m0 + blk * 16 + lrow) * d.Cin + c);
-            glds16(src, __builtin_amdgcn_readfirstlane(sbase + blk * 1024));
+            pa[j] = cv ? reinterpret_cast<const unsigned char*>(Wt + ((size_t)(ltap * d.CoutP + m0 + blk * 16 + lrow) * d.Cin + c))
+                       : g_mg_zeros + (lane & 3) * 16;
         }
 #pragma unroll
         for (int j = 0; j < B_IPS; ++j) {
-            const int blk = wave + NW * j;
             const int iy = b_y[j] + dy, ix = b_x[j] + dx;
-            const void* src = g_mg_zeros;
-            if (cv && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win)
-                src = In + ((size_t)((b_n[j] * d.Hin + iy) * d.Win + ix) * d.Cin + c);
-            glds16(src, __builtin_amdgcn_readfirstlane(sbase + TM * ROWB + blk * 1024));
+            const bool ok = cv && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
+            pb[j] = ok ? reinterpret_cast<const unsigned char*>(In + ((size_t)((b_n[j] * d.Hin + iy) * d.Win + ix) * d.Cin + c))
+                       : g_mg_zeros + (lane & 3) * 16;
+        }
+    };
+    auto issue = [&](int stage, int tap, int chunk) {
+        if (PACK || chunk == 0 || (!tail_ok && chunk == nchunk - 1)) set_tap(tap, chunk);
+        const unsigned sbase = lds0 + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < A_IPS; ++j) {
+            glds16(pa[j], __builtin_amdgcn_readfirstlane(sbase + (wave + NW * j) * 1024));
+            pa[j] += ROWB;
+        }
+#pragma unroll
+        for (int j = 0; j < B_IPS; ++j) {
+            glds16(pb[j], __builtin_amdgcn_readfirstlane(sbase + TM * ROWB + (wave + NW * j) * 1024));
+            pb[j] += ROWB;
         }
     };
 
@@ -548,6 +572,7 @@ extern "C" int mg_conv_taps(const mg_conv_desc* d, void* stream)
     MG_CHECK_ARG(d->Cout > 0 && d->Cout_gemm > 0 && d->CoutP >= d->Cout_gemm && (d->CoutP % 128) == 0,
                  "mg_conv_taps: bad channel counts Cout=%d Cout_gemm=%d CoutP=%d", d->Cout, d->Cout_gemm, d->CoutP);
     MG_CHECK_ARG((long)d->N * d->Hj * d->Wj < (1L << 30), "mg_conv_taps: too many output pixels");
+    MG_CHECK_ARG((long)d->Cin * (d->dtype == MG_BF16 ? 2 : 4) <= 8192, "mg_conv_taps: Cin too large (%d)", d->Cin);
     MG_CHECK_ARG((d->Hj - 1) * d->osy + d->ooy < d->Hout && (d->Wj - 1) * d->osx + d->oox < d->Wout && d->ooy >= 0 && d->oox >= 0,
                  "mg_conv_taps: output grid exceeds output tensor");
     if (d->epilogue == MG_EPI_SPADE) {

@@ -11,17 +11,17 @@ run() { # name counters...
 import csv, collections, glob
 f = glob.glob("$OUT/$name/*counter_collection.csv")
 if not f: print("$name: no counter file", open("$OUT/$name.log").read()[-600:]); raise SystemExit
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f[0])):
-    k = r["Kernel_Name"][:60]
-    agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
-    cnt[(k, r["Counter_Name"])] += 1
+    k = r["Kernel_Name"][:70] + " grid=" + r.get("Grid_Size", "?")
+    agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     if "conv_taps" in k or "wgrad" in k:
-        print("$name", k, {c: round(v / cnt[(k, c)], 1) for c, v in d.items()})
+        print("$name", k, {c: round(sum(v) / len(v), 1) for c, v in d.items()}, "n=", len(next(iter(d.values()))))
 PY
 }
-run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16
-run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU
-run tcc FETCH_SIZE
-run tcw WRITE_SIZE GRBM_GUI_ACTIVE
+run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES
+run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS
+run tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum
+run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
+run tcw GRBM_GUI_ACTIVE
