@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--batch-per-gpu", type=int, default=8)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--mode", default="train", choices=["train", "gfwd"],
+                    help="train = G step + D step (headline); gfwd = BASELINE configs[1]: generator forward only, no_grad, train-mode BN")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -93,9 +95,13 @@ def main():
     trainer = Pix2PixTrainer(opt)
     data = {k: v.cuda() for k, v in synth_batch(a.batch_per_gpu, a.size, seed=1234 + rank).items()}
 
-    def step():
-        trainer.run_generator_one_step(data)
-        trainer.run_discriminator_one_step(data)
+    if a.mode == "train":
+        def step():
+            trainer.run_generator_one_step(data)
+            trainer.run_discriminator_one_step(data)
+    else:
+        def step():
+            trainer.generated = trainer.pix2pix_model(data, mode="inference")
 
     for _ in range(a.warmup):
         step()
@@ -114,6 +120,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     losses = {k: float(v.detach().float().mean()) for k, v in trainer.get_latest_losses().items()}
+    step_gflop_ref = STEP_GFLOP_REFERENCE if a.mode == "train" else F_G
+    step_gflop_min = STEP_GFLOP_MINIMUM if a.mode == "train" else F_G
 
     roof = None
     if rank == 0 and not a.no_roofline:
@@ -122,8 +130,14 @@ def main():
         n, ms, fl = m.summary()
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
         ach = fl / (ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_taps_kernel (fwd + dgrad launches of one train step)",
-                "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")     # tools/pmc_step.sh (rocprofv3 --pmc passes)
+        if a.mode == "train" and a.dtype == "bf16" and a.batch_per_gpu == 8 and a.size == 512 and os.path.exists(tfile):
+            with open(tfile) as fh:
+                traffic = round(json.load(fh)["conv"]["hbm_bytes_per_step"] / 1e9, 2)
+        roof = {"bound": "mfma", "kernel": "conv_taps_glds_kernel (all fwd + dgrad launches of one step)",
+                "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": traffic, "traffic_unit": "GB of HBM per step for the same launches (2*FETCH_SIZE + WRITE_SIZE)",
                 "launches": n, "kernel_ms_per_step": round(ms, 3), "algorithmic_gflop_per_step": round(fl / 1e9, 1)}
     if world > 1:
         dist.barrier()
@@ -133,22 +147,25 @@ def main():
         ms_step = dt / a.steps * 1e3
         value = gbatch * a.steps / dt
         out = {
-            "metric": "training images/sec at 512x512 (G+D step)", "value": round(value, 3), "unit": "images/s",
+            "metric": "training images/sec at 512x512 (G+D step)" if a.mode == "train" else "generator forward images/sec at 512x512",
+            "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if a.dtype == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"SPADEB G + multiscale PatchGAN D + VGG19 loss, full G step + D step (Adam), "
-                                   f"bs={a.batch_per_gpu}/GPU, {a.size}x{a.size}, BASELINE.json configs[2]",
+            "config": {"workload": (f"SPADEB G + multiscale PatchGAN D + VGG19 loss, full G step + D step (Adam), "
+                                    f"bs={a.batch_per_gpu}/GPU, {a.size}x{a.size}, BASELINE.json configs[2]") if a.mode == "train" else
+                                   (f"SPADEB generator forward only (no_grad, train-mode BN), bs={a.batch_per_gpu}/GPU, "
+                                    f"{a.size}x{a.size}, BASELINE.json configs[1]"),
                        "global_batch": gbatch, "batch_per_gpu": a.batch_per_gpu, "resolution": a.size,
                        "parallelism": f"dp{world}", "init": "reference default (xavier, 0.02), random VGG weights"},
-            "step_tflops_effective": {"vs_reference_work_6018GF": round(value * STEP_GFLOP_REFERENCE / 1e3 / world, 1),
-                                      "vs_minimum_work_5344GF": round(value * STEP_GFLOP_MINIMUM / 1e3 / world, 1),
-                                      "unit": "TFLOP/s per GPU"},
+            "step_tflops_effective": {"vs_reference_work": round(value * step_gflop_ref / 1e3 / world, 1),
+                                      "vs_minimum_work": round(value * step_gflop_min / 1e3 / world, 1),
+                                      "gflop_per_image": [step_gflop_ref, step_gflop_min], "unit": "TFLOP/s per GPU"},
             "losses": losses,
         }
         if roof is not None:
             out["roofline"] = roof
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.mode == "train":
             from oracle.cpu_baseline import bounded_baseline
             ips, threads, what = bounded_baseline(a.size)
             out["cpu_baseline"] = {"value": round(ips, 4), "unit": "images/s", "cores": threads, "kind": "port",

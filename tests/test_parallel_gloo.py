@@ -98,3 +98,68 @@ def test_two_ranks_equal_single_process_on_concatenated_batch():
     assert (out2 - single["out"]).abs().max().item() < 5e-5
     for k in ("rm", "rv"):
         assert torch.allclose(got[0][k], got[1][k]) and (got[0][k] - single[k]).abs().max().item() < 1e-5
+
+
+def _trainer_step(rank, world, port, n_total, q):
+    """One generator step + one discriminator step of the full trainer (G, D, VGG loss, flat Adam arenas)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(2)
+    from michigan_amd import _cabi
+    from michigan_amd.model import Pix2PixTrainer
+    from michigan_amd.synth import synth_batch
+    from oracle.cabi_emulator import EmulatorBackend
+    import parity_utils as PU
+    _cabi.set_backend(EmulatorBackend())
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(1234)                          # identical initial weights on every rank (and broadcast anyway)
+    opt = PU.small_opt(ngf=8, ndf=8, crop_size=128, init_type="normal", init_variance=0.3, random_expand_mask=False)
+    tr = Pix2PixTrainer(opt)
+    full = synth_batch(n_total, 128, seed=23)
+    per = n_total // world
+    data = {k: v[rank * per:(rank + 1) * per] for k, v in full.items()}
+    random.seed(7)
+    tr.optimizer_G.zero_grad()
+    tr._set_d_requires_grad(False)
+    g_losses, _ = tr.pix2pix_model(data, mode="generator")
+    sum(g_losses.values()).mean().backward()
+    tr._set_d_requires_grad(True)
+    tr.optimizer_G.sync_grads()
+    g_grad = (tr.optimizer_G.flat_grad / world).numpy().copy()
+    tr.optimizer_D.zero_grad()
+    d_losses = tr.pix2pix_model(data, mode="discriminator")
+    sum(d_losses.values()).mean().backward()
+    tr.optimizer_D.sync_grads()
+    d_grad = (tr.optimizer_D.flat_grad / world).numpy().copy()
+    losses = {k: float(v.detach().float().mean()) for k, v in {**g_losses, **d_losses}.items()}
+    q.put((rank, {"g": g_grad, "d": d_grad, "losses": losses}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1200)
+def test_trainer_two_ranks_match_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_trainer_step, args=(0, 1, 0, 4, q))
+    p.start()
+    _, single = q.get(timeout=900)
+    p.join()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_step, args=(r, 2, port, 4, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=900) for _ in range(2))
+    for p in procs:
+        p.join()
+        assert p.exitcode == 0
+    for key in ("g", "d"):
+        a, b, s = torch.from_numpy(got[0][key]), torch.from_numpy(got[1][key]), torch.from_numpy(single[key])
+        assert torch.equal(a, b), key                                    # all-reduced in place: bitwise equal on both ranks
+        assert (a - s).abs().max().item() < 2e-4 * s.abs().max().item(), key
+    for k, v in single["losses"].items():                                # per-rank means average to the big-batch loss
+        avg = 0.5 * (got[0]["losses"][k] + got[1]["losses"][k])
+        assert abs(avg - v) < 1e-4 * max(1.0, abs(v)), k

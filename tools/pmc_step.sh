@@ -1,0 +1,31 @@
+#!/bin/bash
+# HBM traffic of the conv kernels over one training step (run on the GPU box):
+#   tools/pmc_step.sh   -> gpurun_out/pmc_step/conv_traffic.json
+# Separate --pmc passes for FETCH_SIZE and WRITE_SIZE (TCC has 4 slots; FETCH_SIZE needs 3, WRITE_SIZE 2);
+# gfx950 correction from MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 128-byte requests as 64 B, so the
+# read side is doubled; units are KiB.
+set -u
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_step
+mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-roofline --no-cpu-baseline > $OUT/$c.log 2>&1
+done
+python - <<PY
+import csv, glob, json
+tot = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob("$OUT/%s/*counter_collection.csv" % c)[0]
+    s = {"conv": 0.0, "wgrad": 0.0, "all": 0.0}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != c: continue
+        v = float(r["Counter_Value"]); s["all"] += v
+        if "conv_taps" in r["Kernel_Name"]: s["conv"] += v
+        if "wgrad_kernel" in r["Kernel_Name"]: s["wgrad"] += v
+    tot[c] = s
+steps = 2.0
+res = {k: {"fetch_kib_raw": tot["FETCH_SIZE"][k] / steps, "write_kib": tot["WRITE_SIZE"][k] / steps,
+           "hbm_bytes_per_step": (2 * tot["FETCH_SIZE"][k] + tot["WRITE_SIZE"][k]) * 1024 / steps} for k in ("conv", "wgrad", "all")}
+res["note"] = "per training step (bs 8, 512^2, bf16); read side = 2 x FETCH_SIZE (gfx950 correction), KiB -> bytes"
+json.dump(res, open("$OUT/conv_traffic.json", "w"), indent=1)
+print(json.dumps(res))
+PY
