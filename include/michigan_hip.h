@@ -216,7 +216,8 @@ int mg_probe_mfma_layout(float* out /* [3][64][16] */, void* stream);
 int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* out /* [64][4] */, void* stream);
 
 /* Tuning switch for A/B measurements: key 0 = conv pipeline (0 register-staged double buffer,
- * 1 LDS-DMA three-stage ring, default).  Results are identical either way. */
+ * 1 LDS-DMA three-stage ring, default); key 1 = allow 256x256 tiles; key 2 = 3x3 halo-tile kernel.
+ * Results are identical whatever the setting. */
 int         mg_set_option(int32_t key, int32_t value);
 
 /* sizeof(mg_conv_desc) (which=0) / sizeof(mg_wgrad_desc) (which=1): lets a

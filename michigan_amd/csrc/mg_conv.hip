@@ -14,184 +14,14 @@
 // are issued before the current chunk's MFMAs (latency hides under the matrix
 // pipe).  bf16 uses v_mfma_f32_32x32x16_bf16, f32 uses v_mfma_f32_32x32x2_f32
 // (exact fp32 fma chain) -- same tiling, same LDS image (64 B of K per row).
-#include "mg_common.h"
-#include <type_traits>
 
+int g_mg_conv_halo = 1;          // 3x3 stride-1 convs on the LDS halo-tile kernel (mg_set_option(2, v))
 int g_mg_conv_bigtiles = 1;      // allow the 128x256 / 256x256 tiles (mg_set_option(1, v))
 int g_mg_conv_pipeline = 1;      // 0 = register-staged double buffer, 1 = LDS-DMA 3-stage ring (mg_set_option(0, v))
 
+#include "mg_conv_common.h"
+
 namespace {
-
-constexpr int ROWB = 64;    // bytes of K per LDS row and pipeline stage
-constexpr int NTHR = 256;
-
-struct ConvK {              // kernel-side view of mg_conv_desc (passed by value)
-    const void* in; const void* wt; void* out;
-    const float* bias; const void* resid; const void* x;
-    const float* mean; const float* rstd; void* gamma_out;
-    int N, Hin, Win, Cin;
-    int Hout, Wout, Cout, Cout_gemm, CoutP;
-    int Hj, Wj, isy, isx, osy, osx, ooy, oox;
-    int ntaps, act; float slope;
-    int ngemm;              // N*Hj*Wj
-    int tiles_m;
-    int tpc;                // taps packed into one 64-byte K chunk (tiny Cin), 1 otherwise
-    int tap[MG_MAX_TAPS];   // (dy & 0xffff) | (dx << 16)
-};
-
-// LDS image shared by both pipelines: rows of 64 bytes of K, NO padding; the four 16-byte pieces of a
-// row are XOR-swizzled with (row >> 2) & 3.  ds_write_b128 (8-lane groups = 2 rows x 4 pieces, bank =
-// addr/4 mod 32) and ds_read_b128 (16-lane groups with rows distinct mod 16, bank = addr/4 mod 64) are
-// both conflict-free with it; the previous 80-byte padded rows made every ds_write_b128 2-way
-// (SQ_LDS_BANK_CONFLICT = 1/3 of SQ_LDS_IDX_ACTIVE, profiles/r01_pmc_conv.txt).
-__device__ __forceinline__ int lds_off(int row, int piece) { return row * ROWB + ((piece ^ ((row >> 2) & 3)) << 4); }
-
-template <typename T, int MT, int NT>
-__device__ __forceinline__ void conv_compute(const unsigned char* As, const unsigned char* Bs, int l31, int hi,
-                                             f32x16_t (&acc)[MT][NT])
-{
-    // As/Bs point at this wave's first row; the lane's rows are l31 + 32*t, so (row >> 2) & 3 == (l31 >> 2) & 3
-    const int sw = (l31 >> 2) & 3;
-    if constexpr (sizeof(T) == 2) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t a[MT], b[NT];
-            const int po = ((ks * 2 + hi) ^ sw) << 4;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                a[mt] = *reinterpret_cast<const bf16x8_t*>(As + (mt * 32 + l31) * ROWB + po);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                b[nt] = *reinterpret_cast<const bf16x8_t*>(Bs + (nt * 32 + l31) * ROWB + po);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
-        }
-    } else {
-        // lane (row, hi) owns K elements hi*8 .. hi*8+7 of the 16-float chunk; MFMA j consumes element j
-        // of both halves -- any K permutation is legal as long as A and B use the same one.
-        f32x4_t a[MT][2], b[NT][2];
-        const int p0 = ((hi * 2) ^ sw) << 4, p1 = ((hi * 2 + 1) ^ sw) << 4;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            a[mt][0] = *reinterpret_cast<const f32x4_t*>(As + (mt * 32 + l31) * ROWB + p0);
-            a[mt][1] = *reinterpret_cast<const f32x4_t*>(As + (mt * 32 + l31) * ROWB + p1);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            b[nt][0] = *reinterpret_cast<const f32x4_t*>(Bs + (nt * 32 + l31) * ROWB + p0);
-            b[nt][1] = *reinterpret_cast<const f32x4_t*>(Bs + (nt * 32 + l31) * ROWB + p1);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j >> 2][j & 3], b[nt][j >> 2][j & 3],
-                                                                       acc[mt][nt], 0, 0, 0);
-    }
-}
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f)
-{
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
-
-template <typename T, int MT, int NT, int EPI>
-__device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT][NT], int m0, int q0,
-                                              int wm, int wn, int l31, int hi)
-{
-    const int HWj = d.Hj * d.Wj;
-    // ---- epilogue -----------------------------------------------------------
-    T* __restrict__ Out = reinterpret_cast<T*>(d.out);
-    // compile-time tile indices (static_for): runtime-indexed accumulator arrays would be demoted to scratch
-    static_for<0, NT>([&](auto nt_) {
-        constexpr int nt = decltype(nt_)::value;
-        const int q = q0 + wn * NT * 32 + nt * 32 + l31;
-        if (q >= d.ngemm) return;
-        const int n = q / HWj, r = q - n * HWj;
-        const int jy = r / d.Wj, jx = r - jy * d.Wj;
-        const size_t opix = (size_t)((n * d.Hout + jy * d.osy + d.ooy) * d.Wout + jx * d.osx + d.oox);
-
-        if constexpr (EPI == MG_EPI_PLAIN) {
-            const T* __restrict__ Res = reinterpret_cast<const T*>(d.resid);
-            static_for<0, MT * 4>([&](auto mr_) {
-                {
-                    constexpr int mt = decltype(mr_)::value / 4, rq = decltype(mr_)::value % 4;
-                    const int co = m0 + wm * MT * 32 + mt * 32 + rq * 8 + hi * 4;
-                    if (co >= d.Cout) return;
-                    f32x4_t v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][rq * 4 + j];
-                    if (d.bias) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (co + j < d.Cout_gemm) ? d.bias[co + j] : 0.f;
-                    }
-                    const size_t o = opix * d.Cout + co;
-                    if ((d.Cout & 3) == 0) {
-                        if (Res) { f32x4_t rv = ET<T>::load4(Res + o);
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] += rv[j]; }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = mg_act(v[j], d.act, d.slope);
-                        ET<T>::store4(Out + o, v);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (co + j < d.Cout) {
-                                float s = v[j];
-                                if (Res) s += ET<T>::load1(Res + o + j);
-                                ET<T>::store1(Out + o + j, mg_act(s, d.act, d.slope));
-                            }
-                        }
-                    }
-                }
-            });
-        } else {
-            // SPADE: acc[0] = gamma rows, acc[1] = beta rows of the same 32 output channels.
-            const T* __restrict__ X = reinterpret_cast<const T*>(d.x);
-            T* __restrict__ G1 = reinterpret_cast<T*>(d.gamma_out);
-            const int grow = m0 + wm * 64;              // first GEMM row of this wave's [gamma|beta] block
-            static_for<0, 4>([&](auto rq_) {
-                constexpr int rq = decltype(rq_)::value;
-                const int sub = rq * 8 + hi * 4;
-                const int oc = (grow >> 1) + sub;
-                if (oc >= d.Cout) return;
-                f32x4_t g, bt;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    g[j]  = 1.f + acc[0][nt][rq * 4 + j] + (d.bias ? d.bias[grow + sub + j] : 0.f);
-                    bt[j] = acc[1][nt][rq * 4 + j] + (d.bias ? d.bias[grow + 32 + sub + j] : 0.f);
-                }
-                const size_t o = opix * d.Cout + oc;
-                if ((d.Cout & 3) == 0) {
-                    const f32x4_t xv = ET<T>::load4(X + o);
-                    f32x4_t hv;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float xh = (xv[j] - d.mean[oc + j]) * d.rstd[oc + j];
-                        hv[j] = mg_act(xh * g[j] + bt[j], d.act, d.slope);
-                    }
-                    ET<T>::store4(Out + o, hv);
-                    if (G1) ET<T>::store4(G1 + o, g);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (oc + j < d.Cout) {
-                            const float xh = (ET<T>::load1(X + o + j) - d.mean[oc + j]) * d.rstd[oc + j];
-                            ET<T>::store1(Out + o + j, mg_act(xh * g[j] + bt[j], d.act, d.slope));
-                            if (G1) ET<T>::store1(G1 + o + j, g[j]);
-                        }
-                    }
-                }
-            });
-        }
-    });
-}
 
 template <typename T, int WM, int WN, int MT, int NT, int EPI, bool PACK>
 __global__ __launch_bounds__(NTHR) void conv_taps_kernel(const ConvK d)
@@ -315,7 +145,7 @@ __global__ __launch_bounds__(NTHR) void conv_taps_kernel(const ConvK d)
         __syncthreads();
     }
 
-    conv_epilogue<T, MT, NT, EPI>(d, acc, m0, q0, wm, wn, l31, hi);
+    conv_epilogue<T, MT, NT, EPI>(d, acc, m0, LinearPixMap{d, q0, HWj}, wm, wn, l31, hi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -329,22 +159,6 @@ __global__ __launch_bounds__(NTHR) void conv_taps_kernel(const ConvK d)
 // schedule per K chunk is:  wait(vmcnt = one stage of this wave's loads still in flight) -> s_barrier
 // -> issue chunk it+2 into the slot consumed at it-1 -> MFMAs on chunk it.
 // ---------------------------------------------------------------------------------------------
-// zero source for out-of-image taps / tail rows: long enough to be walked chunk by chunk (<= 8 KiB of K per tap: Cin <= 4096 bf16 / 2048 f32)
-__device__ __attribute__((aligned(64))) unsigned char g_mg_zeros[8192 + 64];
-
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %2\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-
 // Tile geometries: WM x WN waves (4 or 8 per workgroup), each wave MT x NT MFMA 32x32 tiles.
 //   (2,2,2,2) 128co x 128pix   (1,4,2,2) 64 x 256   (2,2,2,4) 128 x 256   (4,2,2,4) 256 x 256 (8 waves)
 // The operand stream comes out of L2 at ~64 B/clk/CU and everything in flight must sit in LDS, so at a
@@ -484,7 +298,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && MT * NT >= 8) ? 2 : 
         islot = (islot == NS - 1) ? 0 : islot + 1;
     }
 
-    conv_epilogue<T, MT, NT, EPI>(d, acc, m0, q0, wm, wn, l31, hi);
+    conv_epilogue<T, MT, NT, EPI>(d, acc, m0, LinearPixMap{d, q0, HWj}, wm, wn, l31, hi);
 }
 
 template <typename T, int WM, int WN, int MT, int NT, int EPI, bool PACK>
@@ -553,9 +367,30 @@ int dispatch_tiles(ConvK& k, hipStream_t st)
     return MG_ERR_UNSUPPORTED;
 }
 
+// 3x3 / stride-1 / same-size convs with whole K chunks go to the halo-tile kernel (mg_conv_halo.hip)
+template <typename T>
+bool halo_applies(const ConvK& k)
+{
+    constexpr int CH = ROWB / (int)sizeof(T);
+    if (!g_mg_conv_halo || g_mg_conv_pipeline != 1) return false;
+    if (k.ntaps != 9 || k.isy != 1 || k.isx != 1 || k.osy != 1 || k.osx != 1 || k.ooy != 0 || k.oox != 0) return false;
+    if (k.Hj != k.Hin || k.Wj != k.Win || k.Hout != k.Hin || k.Wout != k.Win) return false;
+    if (k.Cin % CH || k.Cout_gemm <= 64 || k.Hin < 8 || k.Win < 16) return false;
+    unsigned seen = 0;
+    for (int t = 0; t < 9; ++t) {
+        const int dy = (int)(short)(k.tap[t] & 0xffff), dx = k.tap[t] >> 16;
+        if (dy < -1 || dy > 1 || dx < -1 || dx > 1) return false;
+        seen |= 1u << ((dy + 1) * 3 + dx + 1);
+    }
+    if (seen != 0x1ffu) return false;
+    const long wgs = (long)k.N * ((k.Hin + 7) / 8) * ((k.Win + 15) / 16) * ((k.Cout_gemm + 127) / 128);
+    return wgs >= 384;
+}
+
 template <typename T>
 int dispatch_conv(ConvK& k, int epilogue, hipStream_t st)
 {
+    if (halo_applies<T>(k)) return launch_conv_halo(k, ET<T>::DT, epilogue, st);
     return epilogue == MG_EPI_SPADE ? dispatch_tiles<T, MG_EPI_SPADE>(k, st) : dispatch_tiles<T, MG_EPI_PLAIN>(k, st);
 }
 
@@ -590,7 +425,7 @@ extern "C" int mg_conv_taps(const mg_conv_desc* d, void* stream)
     k.Hj = d->Hj; k.Wj = d->Wj; k.isy = d->isy; k.isx = d->isx;
     k.osy = d->osy; k.osx = d->osx; k.ooy = d->ooy; k.oox = d->oox;
     k.ntaps = d->ntaps; k.act = d->act; k.slope = d->slope;
-    k.ngemm = d->N * d->Hj * d->Wj; k.tiles_m = 0; k.tpc = 1;
+    k.ngemm = d->N * d->Hj * d->Wj; k.tiles_m = 0; k.tpc = 1; k.tiles_y = k.tiles_x = 0;
     for (int t = 0; t < MG_MAX_TAPS; ++t)
         k.tap[t] = t < d->ntaps ? (int)((((uint32_t)(int)d->tap_dy[t]) & 0xffffu) | (((uint32_t)(int)d->tap_dx[t]) << 16)) : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -601,5 +436,6 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
 {
     if (key == 0 && (value == 0 || value == 1)) { g_mg_conv_pipeline = value; return MG_OK; }
     if (key == 1 && (value == 0 || value == 1)) { g_mg_conv_bigtiles = value; return MG_OK; }
+    if (key == 2 && (value == 0 || value == 1)) { g_mg_conv_halo = value; return MG_OK; }
     return mg_fail(MG_ERR_ARG, "mg_set_option: unknown key/value %d/%d", key, value);
 }

@@ -48,11 +48,13 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--pipeline", type=int, default=1, help="0 register-staged, 1 LDS-DMA ring")
     ap.add_argument("--bigtiles", type=int, default=1)
+    ap.add_argument("--halo", type=int, default=1)
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     from michigan_amd import _cabi
     _cabi.backend().mg_set_option(0, a.pipeline)
     _cabi.backend().mg_set_option(1, a.bigtiles)
+    _cabi.backend().mg_set_option(2, a.halo)
     print(f"{'shape':28s} {'GF':>8s} | {'fwd ms':>8s} {'TF/s':>7s} | {'dgrad ms':>8s} {'TF/s':>7s} | {'wgrad ms':>8s} {'TF/s':>7s}")
     for name, cin, cout, k, s, p, H in SHAPES:
         if a.only and a.only not in name:
