@@ -375,7 +375,8 @@ bool halo_applies(const ConvK& k)
     if (!g_mg_conv_halo || g_mg_conv_pipeline != 1) return false;
     if (k.ntaps != 9 || k.isy != 1 || k.isx != 1 || k.osy != 1 || k.osx != 1 || k.ooy != 0 || k.oox != 0) return false;
     if (k.Hj != k.Hin || k.Wj != k.Win || k.Hout != k.Hin || k.Wout != k.Win) return false;
-    if (k.Cin % CH || k.Cout_gemm <= 64 || k.Hin < 8 || k.Win < 16) return false;
+    if (k.Cin % CH || k.Cout_gemm <= 32 || k.Hin < 8 || k.Win < 16) return false;
+    if (k.Cout_gemm <= 64 && k.Hin < 16) return false;
     unsigned seen = 0;
     for (int t = 0; t < 9; ++t) {
         const int dy = (int)(short)(k.tap[t] & 0xffff), dx = k.tap[t] >> 16;
@@ -383,7 +384,8 @@ bool halo_applies(const ConvK& k)
         seen |= 1u << ((dy + 1) * 3 + dx + 1);
     }
     if (seen != 0x1ffu) return false;
-    const long wgs = (long)k.N * ((k.Hin + 7) / 8) * ((k.Win + 15) / 16) * ((k.Cout_gemm + 127) / 128);
+    const int th = k.Cout_gemm <= 64 ? 16 : 8, tmh = k.Cout_gemm <= 64 ? 64 : 128;
+    const long wgs = (long)k.N * ((k.Hin + th - 1) / th) * ((k.Win + 15) / 16) * ((k.Cout_gemm + tmh - 1) / tmh);
     return wgs >= 384;
 }
 

@@ -16,18 +16,32 @@
 
 namespace {
 
-constexpr int TH = 8, TW = 16, PW = TW + 2;
-constexpr int PROWS = (TH + 2) * PW;          // 180 patch rows (pixels) of 64 bytes
-constexpr int PBLK = 12;                      // 16-row LDS-DMA blocks per patch (192 rows)
-constexpr int PSTAGE = PBLK * 1024;
-constexpr int TM_H = 128;
-constexpr int ASTAGE = TM_H * ROWB;
-constexpr int LDS_HALO = 3 * ASTAGE + 2 * PSTAGE;
+constexpr int TW = 16, PW = TW + 2;
 
-template <typename T, int EPI>
+// Two geometries (4 waves, each 64 channels x 64 pixels = 2x2 MFMA tiles):
+//   WM=2: 128 channels x  8x16 pixels, patch 10x18 = 180 rows (12 DMA blocks), weights 8 KiB per tap
+//   WM=1:  64 channels x 16x16 pixels, patch 18x18 = 324 rows (24 DMA blocks), weights 4 KiB per tap
+//          (the 64-channel layers at 512^2 -- up_3, VGG conv1_2 -- stage 3.2x fewer bytes per FLOP than on
+//          the generic 64x256 tile)
+template <int WM> struct HaloGeom {
+    static constexpr int WN = 4 / WM;
+    static constexpr int TM = WM * 64;
+    static constexpr int TH = WN * 64 / TW;                    // 8 or 16
+    static constexpr int PROWS = (TH + 2) * PW;
+    static constexpr int PBLK = ((PROWS + 15) / 16 + 3) / 4 * 4;   // whole blocks per wave
+    static constexpr int PSTAGE = PBLK * 1024;
+    static constexpr int ASTAGE = TM * ROWB;
+    static constexpr int A_IPS = TM / 64, P_IPS = PBLK / 4;
+    static constexpr int LDS = 3 * ASTAGE + 2 * PSTAGE;
+};
+
+template <typename T, int EPI, int WM>
 __global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
 {
-    constexpr int MT = 2, NT = 2, WN = 2;
+    using G = HaloGeom<WM>;
+    constexpr int MT = 2, NT = 2, WN = G::WN;
+    constexpr int TH = G::TH, PROWS = G::PROWS, PSTAGE = G::PSTAGE, ASTAGE = G::ASTAGE, TM_H = G::TM;
+    constexpr int A_IPS = G::A_IPS, P_IPS = G::P_IPS;
     constexpr int EPP = 16 / (int)sizeof(T);
     constexpr int CH  = ROWB / (int)sizeof(T);
 
@@ -61,9 +75,9 @@ __global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
     const unsigned char* const zsrc = g_mg_zeros + (lane & 3) * 16;
 
     // patch source pointers: fixed pixels, walked +64 B per channel chunk
-    const unsigned char* pp[3];
+    const unsigned char* pp[P_IPS];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < P_IPS; ++j) {
         const int r = (wave + 4 * j) * 16 + lrow;
         const int pr = r / PW, pc = r - pr * PW;
         const int iy = y0 + pr - 1, ix = x0 + pc - 1;
@@ -71,9 +85,9 @@ __global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
         pp[j] = ok ? reinterpret_cast<const unsigned char*>(In + ((size_t)((img * d.Hin + iy) * d.Win + ix) * d.Cin + piece * EPP)) : zsrc;
     }
     // weight source pointers for (tap 0, chunk 0)
-    const unsigned char* pa0[2];
+    const unsigned char* pa0[A_IPS];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < A_IPS; ++j)
         pa0[j] = reinterpret_cast<const unsigned char*>(Wt + ((size_t)(m0 + (wave + 4 * j) * 16 + lrow) * d.Cin + piece * EPP));
     const size_t tapstride = (size_t)d.CoutP * d.Cin * sizeof(T);
 
@@ -83,7 +97,7 @@ __global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
     auto issue_patch = [&](int buf) {
         const unsigned base = lds0 + 3 * ASTAGE + buf * PSTAGE;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < P_IPS; ++j) {
             glds16(pp[j], __builtin_amdgcn_readfirstlane(base + (wave + 4 * j) * 1024));
             pp[j] += ROWB;
         }
@@ -92,7 +106,7 @@ __global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
         const unsigned base = lds0 + slot * ASTAGE;
         const size_t off = (size_t)tap * tapstride + (size_t)chunk * ROWB;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < A_IPS; ++j)
             glds16(pa0[j] + off, __builtin_amdgcn_readfirstlane(base + (wave + 4 * j) * 1024));
     };
 
@@ -109,7 +123,7 @@ __global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int p = wn * 64 + nt * 32 + l31;
-        prow0[nt] = ((p >> 4) + 1) * PW + (p & 15) + 1;
+        prow0[nt] = ((p >> 4) + 1) * PW + (p & 15) + 1;      // TW == 16
     }
     const int swa = (l31 >> 2) & 3;
 
@@ -169,9 +183,9 @@ __global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
             constexpr int t = decltype(t_)::value;
             // loads younger than the weights of this tap: next tap's weights (2 per wave) and, right after
             // a chunk started, the next chunk's patch (3 per wave) -- see the issue order below
-            if constexpr (t == 1 || t == 2) { if (next_chunk) wait_vmcnt<5>(); else wait_vmcnt<2>(); }
-            else if constexpr (t == 8)      { if (next_chunk) wait_vmcnt<2>(); else wait_vmcnt<0>(); }
-            else                            wait_vmcnt<2>();
+            if constexpr (t == 1 || t == 2) { if (next_chunk) wait_vmcnt<A_IPS + P_IPS>(); else wait_vmcnt<A_IPS>(); }
+            else if constexpr (t == 8)      { if (next_chunk) wait_vmcnt<A_IPS>(); else wait_vmcnt<0>(); }
+            else                            wait_vmcnt<A_IPS>();
             __builtin_amdgcn_s_barrier();
             // weights two taps ahead into the ring slot consumed at the previous tap
             if constexpr (t < 7) issue_a((t + 2) % 3, t + 2, c);
@@ -191,17 +205,25 @@ __global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
     conv_epilogue<T, MT, NT, EPI>(d, acc, m0, pixmap, wm, wn, l31, hi);
 }
 
-template <typename T, int EPI>
-int launch_halo(ConvK& k, hipStream_t st)
+template <typename T, int EPI, int WM>
+int launch_halo_g(ConvK& k, hipStream_t st)
 {
-    k.tiles_m = (k.Cout_gemm + TM_H - 1) / TM_H;
-    k.tiles_y = (k.Hin + TH - 1) / TH;
+    using G = HaloGeom<WM>;
+    k.tiles_m = (k.Cout_gemm + G::TM - 1) / G::TM;
+    k.tiles_y = (k.Hin + G::TH - 1) / G::TH;
     k.tiles_x = (k.Win + TW - 1) / TW;
     const long nblk = (long)k.N * k.tiles_y * k.tiles_x * k.tiles_m;
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_taps(halo): bad grid %ld", nblk);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, EPI>), dim3((unsigned)nblk), dim3(NTHR), LDS_HALO, st, k);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, EPI, WM>), dim3((unsigned)nblk), dim3(NTHR), G::LDS, st, k);
     MG_CHECK_LAUNCH("mg_conv_taps(halo)");
     return MG_OK;
+}
+
+template <typename T, int EPI>
+int launch_halo(ConvK& k, hipStream_t st)
+{
+    if (k.Cout_gemm <= 64) return launch_halo_g<T, EPI, 1>(k, st);
+    return launch_halo_g<T, EPI, 2>(k, st);
 }
 
 }  // namespace
