@@ -80,9 +80,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("MG_BENCH_BACKEND", "nccl")       # "gloo" lets two ranks share one GPU in a smoke test
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from michigan_amd import _cabi
@@ -124,21 +129,24 @@ def main():
     step_gflop_min = STEP_GFLOP_MINIMUM if a.mode == "train" else F_G
 
     roof = None
-    if rank == 0 and not a.no_roofline:
+    if not a.no_roofline:
+        # one extra, untimed step with HIP-event timing of every conv launch.  EVERY rank runs it (the step
+        # contains collectives); only rank 0 reports.
         with ConvMeter() as m:
             step()
         n, ms, fl = m.summary()
-        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
-        ach = fl / (ms * 1e-3) / 1e12
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")     # tools/pmc_step.sh (rocprofv3 --pmc passes)
-        if a.mode == "train" and a.dtype == "bf16" and a.batch_per_gpu == 8 and a.size == 512 and os.path.exists(tfile):
-            with open(tfile) as fh:
-                traffic = round(json.load(fh)["conv"]["hbm_bytes_per_step"] / 1e9, 2)
-        roof = {"bound": "mfma", "kernel": "conv_taps_glds_kernel (all fwd + dgrad launches of one step)",
-                "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                "traffic": traffic, "traffic_unit": "GB of HBM per step for the same launches (2*FETCH_SIZE + WRITE_SIZE)",
-                "launches": n, "kernel_ms_per_step": round(ms, 3), "algorithmic_gflop_per_step": round(fl / 1e9, 1)}
+        if rank == 0:
+            peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+            ach = fl / (ms * 1e-3) / 1e12
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")     # tools/pmc_step.sh (rocprofv3 --pmc passes)
+            if a.mode == "train" and a.dtype == "bf16" and a.batch_per_gpu == 8 and a.size == 512 and os.path.exists(tfile):
+                with open(tfile) as fh:
+                    traffic = round(json.load(fh)["conv"]["hbm_bytes_per_step"] / 1e9, 2)
+            roof = {"bound": "mfma", "kernel": "conv3x3_halo_kernel + conv_taps_glds_kernel (all fwd + dgrad conv launches of one step)",
+                    "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "traffic": traffic, "traffic_unit": "GB of HBM per step for the same launches (2*FETCH_SIZE + WRITE_SIZE)",
+                    "launches": n, "kernel_ms_per_step": round(ms, 3), "algorithmic_gflop_per_step": round(fl / 1e9, 1)}
     if world > 1:
         dist.barrier()
 
