@@ -101,11 +101,13 @@ int mg_conv_taps(const mg_conv_desc* d, void* stream);
  * dw is fp32 and is ACCUMULATED INTO with hardware float atomics (caller
  * zeroes it).  dy has Cg channels per pixel in GEMM row order (for the fused
  * SPADE conv that is the [gamma|beta] block order).  Cg and Cin multiples of 8.
+ * If dbias != NULL the bias gradient (column sums of dy) is accumulated into it by the same launch.
  * ------------------------------------------------------------------------- */
 typedef struct mg_wgrad_desc {
     const void* x;         /* [N][Hin][Win][Cin]                              */
     const void* dy;        /* [N][Hj][Wj][Cg]                                 */
     float*      dw;        /* [ntaps][Cg][Cin] fp32                           */
+    float*      dbias;     /* optional [Cg] fp32: += sum over pixels of dy    */
     int32_t dtype;
     int32_t N, Hin, Win, Cin;
     int32_t Hj, Wj, Cg;

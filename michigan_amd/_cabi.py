@@ -37,7 +37,7 @@ class ConvDesc(ctypes.Structure):
 class WgradDesc(ctypes.Structure):
     """struct mg_wgrad_desc (include/michigan_hip.h)."""
     _fields_ = [
-        ("x", _vp), ("dy", _vp), ("dw", _vp),
+        ("x", _vp), ("dy", _vp), ("dw", _vp), ("dbias", _vp),
         ("dtype", _i32), ("N", _i32), ("Hin", _i32), ("Win", _i32), ("Cin", _i32),
         ("Hj", _i32), ("Wj", _i32), ("Cg", _i32), ("isy", _i32), ("isx", _i32),
         ("ntaps", _i32), ("splitk", _i32), ("flags", _i32),

@@ -19,7 +19,7 @@ namespace {
 constexpr int NTHR = 256;
 
 struct WgK {
-    const void* x; const void* dy; float* dw;
+    const void* x; const void* dy; float* dw; float* dbias;
     int N, Hin, Win, Cin, Hj, Wj, Cg, isy, isx, ntaps;
     int K;            // N*Hj*Wj
     int kper;         // pixels per split (multiple of KP)
@@ -118,6 +118,26 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgK d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+    // Fused bias gradient: the workgroups of the first N tile / tap group also column-sum the dY pieces
+    // they stage anyway (dbias[co] = sum over pixels of dY), replacing a separate full pass over dY.
+    const bool do_bias = d.dbias != nullptr && tg == 0 && tn == 0;
+    float bsum[EPP];
+#pragma unroll
+    for (int j = 0; j < EPP; ++j) bsum[j] = 0.f;
+    auto bias_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const uint32_t w[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            if constexpr (BF) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bsum[2 * j] += __uint_as_float(w[j] << 16); bsum[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bsum[j] += __uint_as_float(w[j]);
+            }
+        }
+    };
+
     auto compute = [&](int s) {
         const unsigned char* As = smem + s * STAGE;
         const unsigned char* Bs = As + OPB;
@@ -187,14 +207,26 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgK d)
 
     const int nk = (kend - kbeg + KP - 1) / KP;
     gload(kbeg);
+    if (do_bias) bias_acc();
     lstore(0);
     __syncthreads();
     for (int it = 0; it < nk; ++it) {
         const bool more = (it + 1 < nk);
         if (more) gload(kbeg + (it + 1) * KP);
         compute(it & 1);
-        if (more) lstore((it + 1) & 1);
+        if (more) { if (do_bias) bias_acc(); lstore((it + 1) & 1); }
         __syncthreads();
+    }
+    if (do_bias) {                       // reduce the RPP thread rows through the (idle) LDS, one atomic per channel
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int j = 0; j < EPP; ++j) red[prow * 128 + piece * EPP + j] = bsum[j];
+        __syncthreads();
+        if (tid < 128 && m0 + tid < d.Cg) {
+            float t = 0.f;
+            for (int r = 0; r < RPP; ++r) t += red[r * 128 + tid];
+            atomicAdd(d.dbias + m0 + tid, t);
+        }
     }
 
     // ---- accumulate the tile into dW (fp32 atomics; lanes 0..31 = 32 consecutive ci)
@@ -257,7 +289,7 @@ extern "C" int mg_conv_wgrad(const mg_wgrad_desc* d, void* stream)
     MG_CHECK_ARG(d->N > 0 && d->Hj > 0 && d->Wj > 0 && d->Hin > 0 && d->Win > 0, "mg_conv_wgrad: empty geometry");
     MG_CHECK_ARG((long)d->N * d->Hj * d->Wj < (1L << 30), "mg_conv_wgrad: too many pixels");
     WgK k;
-    k.x = d->x; k.dy = d->dy; k.dw = d->dw;
+    k.x = d->x; k.dy = d->dy; k.dw = d->dw; k.dbias = d->dbias;
     k.N = d->N; k.Hin = d->Hin; k.Win = d->Win; k.Cin = d->Cin;
     k.Hj = d->Hj; k.Wj = d->Wj; k.Cg = d->Cg; k.isy = d->isy; k.isx = d->isx; k.ntaps = d->ntaps;
     k.K = d->N * d->Hj * d->Wj; k.splitk = d->splitk; k.kper = 0; k.tiles_m = k.tiles_n = 0; k.tpt = 1;

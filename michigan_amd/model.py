@@ -88,11 +88,16 @@ class Pix2PixModel(nn.Module):
                          input_tag=d["input_tag"], noise=d["noise"], image_tag=d["image_tag"])
 
     def discriminate(self, d, fake_image):
-        orient = self.orientation_planes(d).to(fake_image.dtype)
-        tag = d["input_tag"].to(fake_image.dtype)
-        fake = torch.cat([tag, orient, fake_image], dim=1)
-        real = torch.cat([tag, orient, d["image_tag"].to(fake_image.dtype)], dim=1)
-        out = self.netD(torch.cat([fake, real], dim=0))
+        """D([tag one-hot | orientation | image]) on fake and real stacked along the batch
+        (pix2pix_model.py:546-594).  The 7-channel input is assembled directly in the kernels' NHWC layout
+        (+1 zero channel so that a pixel is 16 bytes) instead of an NCHW concat followed by a transpose."""
+        from . import ops
+        dt = fake_image.dtype
+        cond = ops.to_nhwc(torch.cat([d["input_tag"], self.orientation_planes(d)], dim=1), dt)      # [N,H,W,4]
+        zero = cond.new_zeros(cond.shape[:3] + (1,))
+        fake = torch.cat([cond, fake_image.permute(0, 2, 3, 1), zero], dim=3)
+        real = torch.cat([cond, ops.to_nhwc(d["image_tag"], dt), zero], dim=3)
+        out = self.netD(torch.cat([fake, real], dim=0).permute(0, 3, 1, 2))
         half = lambda t: t.size(0) // 2
         pred_fake = [[t[:half(t)] for t in p] for p in out]
         pred_real = [[t[half(t):] for t in p] for p in out]

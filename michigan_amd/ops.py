@@ -176,14 +176,17 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, kh: int, kw: int, stride: int
     return dx
 
 
-def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int, pad: int) -> torch.Tensor:
-    """dW in GEMM order [T, Cg8, Cin] (fp32) of a forward conv; split-K over pixels, fp32 atomics."""
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int, pad: int, want_bias: bool = False):
+    """dW in GEMM order [T, Cg8, Cin] (fp32) of a forward conv; split-K over pixels, fp32 atomics.
+    want_bias=True also returns the bias gradient [Cg8] (column sums of dy) from the same launch."""
     n, h, w, cin = x.shape
     _, hj, wj, cg8 = dy.shape
     taps = fwd_taps(kh, kw, pad)
     dw = torch.zeros((len(taps), cg8, cin), dtype=torch.float32, device=x.device)
+    dbias = torch.zeros(cg8, dtype=torch.float32, device=x.device) if want_bias else None
     d = C.WgradDesc()
     d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
+    d.dbias = dbias.data_ptr() if want_bias else None
     d.dtype = _dt(x)
     d.N, d.Hin, d.Win, d.Cin = n, h, w, cin
     d.Hj, d.Wj, d.Cg = hj, wj, cg8
@@ -193,7 +196,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int,
     _set_taps(d, taps)
     assert dy.dtype == x.dtype
     C.backend().mg_conv_wgrad(d, _stream(x))
-    return dw
+    return (dw, dbias) if want_bias else dw
 
 
 def channel_sums(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
@@ -257,9 +260,13 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = pack_weight(weight, None, x.dtype, _roundup(cx, 128), dpre8.shape[3], 1)
             dx = conv_dgrad(dpre8, wt, kh, kw, stride, pad, (x.shape[1], x.shape[2]), cx)
+        need_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = unpack_wgrad(conv_wgrad(x, dpre8, kh, kw, stride, pad), weight.shape)
-        if has_bias and ctx.needs_input_grad[2]:
+            res = conv_wgrad(x, dpre8, kh, kw, stride, pad, want_bias=need_b)
+            if need_b:
+                dbias = res[1][:cout]
+            dw = unpack_wgrad(res[0] if need_b else res, weight.shape)
+        elif need_b:
             dbias = channel_sums(dpre8)[0, 0, :cout]
         dres = dpre if (has_resid and ctx.needs_input_grad[3]) else None
         return dx, dw, dbias, dres, None, None, None, None
@@ -370,10 +377,17 @@ class _SpadeFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             wt = pack_weight(w_gamma, w_beta, x.dtype, _roundup(actv.shape[3], 128), rows, 1)
             dactv = conv_dgrad(dgb, wt, kh, kh, 1, pad, (hh, ww), actv.shape[3])
-        if ctx.needs_input_grad[2] or ctx.needs_input_grad[4]:
-            dwg, dwb = unpack_wgrad(conv_wgrad(actv, dgb, kh, kh, 1, pad), w_gamma.shape, two=True)
-        if ctx.needs_input_grad[3] or ctx.needs_input_grad[5]:
-            db = channel_sums(dgb)[0, 0].reshape(rows // 64, 2, 32)
+        need_w = ctx.needs_input_grad[2] or ctx.needs_input_grad[4]
+        need_b = ctx.needs_input_grad[3] or ctx.needs_input_grad[5]
+        db = None
+        if need_w:
+            res = conv_wgrad(actv, dgb, kh, kh, 1, pad, want_bias=need_b)
+            dwg, dwb = unpack_wgrad(res[0] if need_b else res, w_gamma.shape, two=True)
+            db = res[1] if need_b else None
+        elif need_b:
+            db = channel_sums(dgb)[0, 0]
+        if db is not None:
+            db = db.reshape(rows // 64, 2, 32)
             dbg, dbb = db[:, 0].reshape(-1)[:c], db[:, 1].reshape(-1)[:c]
         return dx, dactv, dwg, dbg, dwb, dbb, None, None, None, None, None
 

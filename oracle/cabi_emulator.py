@@ -133,6 +133,8 @@ class EmulatorBackend:
         for t in range(d.ntaps):
             g = _gather(x, d.Hj, d.Wj, d.isy, d.isx, int(d.tap_dy[t]), int(d.tap_dx[t])).reshape(-1, d.Cin)
             dw[t] += (dy.t() @ g).float()
+        if _addr(d.dbias):
+            _view(d.dbias, (d.Cg,), torch.float32)[:] += dy.sum(0).float()
         return 0
 
     # -- statistics / norms ------------------------------------------------------
