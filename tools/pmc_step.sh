@@ -19,7 +19,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != c: continue
         v = float(r["Counter_Value"]); s["all"] += v
-        if "conv_taps" in r["Kernel_Name"]: s["conv"] += v
+        if "conv_taps" in r["Kernel_Name"] or "conv3x3_halo" in r["Kernel_Name"]: s["conv"] += v
         if "wgrad_kernel" in r["Kernel_Name"]: s["wgrad"] += v
     tot[c] = s
 steps = 2.0
