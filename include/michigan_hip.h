@@ -181,13 +181,13 @@ int mg_avgpool3s2_bwd(const void* dy, void* dx, int32_t dtype, int32_t N, int32_
 int mg_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int mg_maxpool2_bwd(const void* dy, const void* x, void* dx, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 
-/* background blend  y = bg * (1 - hair[p]) + x * (1 - back[p])
- * (generator.py:186,197,208,219); hair/back are fp32 [P] single-channel masks.
- * bwd: dbg = dy * (1 - hair), dx = dy * (1 - back). */
+/* background blend  y = act(bg * (1 - hair[p]) + x * (1 - back[p]))
+ * (generator.py:186,197,208,219; act = LeakyReLU after the last block, generator.py:227); hair/back are
+ * fp32 [P] single-channel masks.  bwd: dpre = dy * act'(y); dbg = dpre * (1 - hair), dx = dpre * (1 - back). */
 int mg_blend_fwd(const void* bg, const void* x, const float* hair, const float* back, void* y,
-                 int32_t dtype, int64_t P, int32_t C, void* stream);
-int mg_blend_bwd(const void* dy, const float* hair, const float* back, void* dbg, void* dx,
-                 int32_t dtype, int64_t P, int32_t C, void* stream);
+                 int32_t dtype, int64_t P, int32_t C, int32_t act, float slope, void* stream);
+int mg_blend_bwd(const void* dy, const void* y, const float* hair, const float* back, void* dbg, void* dx,
+                 int32_t dtype, int64_t P, int32_t C, int32_t act, float slope, void* stream);
 
 /* Parameter re-layout (host-side glue of every conv call, as ONE launch each):
  * mg_pack_weight : reference fp32 [cout][cin][taps] (one tensor, or gamma+beta for the fused SPADE

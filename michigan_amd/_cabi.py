@@ -61,8 +61,8 @@ _PROTOS = {
     "mg_avgpool3s2_bwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_maxpool2_fwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_maxpool2_bwd": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
-    "mg_blend_fwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp], _i32),
-    "mg_blend_bwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp], _i32),
+    "mg_blend_fwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _vp], _i32),
+    "mg_blend_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _vp], _i32),
     "mg_pack_weight": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_unpack_wgrad": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_l1_mean_fwd": ([_vp, _vp, _i32, _i64, _vp, _vp, _vp], _i32),

@@ -165,7 +165,7 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const T* __restrict
 
 template <typename T>
 __global__ void blend_fwd_kernel(const T* __restrict__ bg, const T* __restrict__ x, const float* __restrict__ hair,
-                                 const float* __restrict__ back, T* __restrict__ y, int64_t nquads, int C)
+                                 const float* __restrict__ back, T* __restrict__ y, int64_t nquads, int C, int act, float slope)
 {
     const int c4 = C / 4;
     GRID_STRIDE(i, nquads) {
@@ -174,19 +174,25 @@ __global__ void blend_fwd_kernel(const T* __restrict__ bg, const T* __restrict__
         const f32x4_t b = ET<T>::load4(bg + i * 4), v = ET<T>::load4(x + i * 4);
         f32x4_t o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = b[j] * wb + v[j] * wx;
+        for (int j = 0; j < 4; ++j) o[j] = mg_act(b[j] * wb + v[j] * wx, act, slope);
         ET<T>::store4(y + i * 4, o);
     }
 }
 template <typename T>
-__global__ void blend_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ hair, const float* __restrict__ back,
-                                 T* __restrict__ dbg, T* __restrict__ dx, int64_t nquads, int C)
+__global__ void blend_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, const float* __restrict__ hair,
+                                 const float* __restrict__ back, T* __restrict__ dbg, T* __restrict__ dx, int64_t nquads, int C,
+                                 int act, float slope)
 {
     const int c4 = C / 4;
     GRID_STRIDE(i, nquads) {
         const int64_t p = i / c4;
         const float wb = 1.f - hair[p], wx = 1.f - back[p];
-        const f32x4_t d = ET<T>::load4(dy + i * 4);
+        f32x4_t d = ET<T>::load4(dy + i * 4);
+        if (act != MG_ACT_NONE) {
+            const f32x4_t yv = ET<T>::load4(y + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] *= mg_act_grad_from_out(yv[j], act, slope);
+        }
         f32x4_t a, b;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { a[j] = d[j] * wb; b[j] = d[j] * wx; }
@@ -386,26 +392,26 @@ extern "C" int mg_maxpool2_bwd(const void* dy, const void* x, void* dx, int32_t 
 }
 
 extern "C" int mg_blend_fwd(const void* bg, const void* x, const float* hair, const float* back, void* y,
-                            int32_t dtype, int64_t P, int32_t C, void* stream)
+                            int32_t dtype, int64_t P, int32_t C, int32_t act, float slope, void* stream)
 {
     MG_CHECK_ARG(bg && x && hair && back && y, "mg_blend_fwd: null pointer");
     MG_CHECK_ARG((dtype == MG_F32 || dtype == MG_BF16) && P > 0 && C > 0 && (C % 4) == 0, "mg_blend_fwd: bad geometry");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t nq = P * (C / 4);
-    if (dtype == MG_BF16) hipLaunchKernelGGL(blend_fwd_kernel<uint16_t>, dim3(ew_grid(nq)), dim3(NTHR), 0, st, (const uint16_t*)bg, (const uint16_t*)x, hair, back, (uint16_t*)y, nq, C);
-    else hipLaunchKernelGGL(blend_fwd_kernel<float>, dim3(ew_grid(nq)), dim3(NTHR), 0, st, (const float*)bg, (const float*)x, hair, back, (float*)y, nq, C);
+    if (dtype == MG_BF16) hipLaunchKernelGGL(blend_fwd_kernel<uint16_t>, dim3(ew_grid(nq)), dim3(NTHR), 0, st, (const uint16_t*)bg, (const uint16_t*)x, hair, back, (uint16_t*)y, nq, C, act, slope);
+    else hipLaunchKernelGGL(blend_fwd_kernel<float>, dim3(ew_grid(nq)), dim3(NTHR), 0, st, (const float*)bg, (const float*)x, hair, back, (float*)y, nq, C, act, slope);
     MG_CHECK_LAUNCH("mg_blend_fwd");
     return MG_OK;
 }
-extern "C" int mg_blend_bwd(const void* dy, const float* hair, const float* back, void* dbg, void* dx,
-                            int32_t dtype, int64_t P, int32_t C, void* stream)
+extern "C" int mg_blend_bwd(const void* dy, const void* y, const float* hair, const float* back, void* dbg, void* dx,
+                            int32_t dtype, int64_t P, int32_t C, int32_t act, float slope, void* stream)
 {
-    MG_CHECK_ARG(dy && hair && back && (dbg || dx), "mg_blend_bwd: null pointer");
+    MG_CHECK_ARG(dy && hair && back && (dbg || dx) && (y || act == MG_ACT_NONE), "mg_blend_bwd: null pointer");
     MG_CHECK_ARG((dtype == MG_F32 || dtype == MG_BF16) && P > 0 && C > 0 && (C % 4) == 0, "mg_blend_bwd: bad geometry");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t nq = P * (C / 4);
-    if (dtype == MG_BF16) hipLaunchKernelGGL(blend_bwd_kernel<uint16_t>, dim3(ew_grid(nq)), dim3(NTHR), 0, st, (const uint16_t*)dy, hair, back, (uint16_t*)dbg, (uint16_t*)dx, nq, C);
-    else hipLaunchKernelGGL(blend_bwd_kernel<float>, dim3(ew_grid(nq)), dim3(NTHR), 0, st, (const float*)dy, hair, back, (float*)dbg, (float*)dx, nq, C);
+    if (dtype == MG_BF16) hipLaunchKernelGGL(blend_bwd_kernel<uint16_t>, dim3(ew_grid(nq)), dim3(NTHR), 0, st, (const uint16_t*)dy, (const uint16_t*)y, hair, back, (uint16_t*)dbg, (uint16_t*)dx, nq, C, act, slope);
+    else hipLaunchKernelGGL(blend_bwd_kernel<float>, dim3(ew_grid(nq)), dim3(NTHR), 0, st, (const float*)dy, (const float*)y, hair, back, (float*)dbg, (float*)dx, nq, C, act, slope);
     MG_CHECK_LAUNCH("mg_blend_bwd");
     return MG_OK;
 }

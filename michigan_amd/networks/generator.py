@@ -84,10 +84,12 @@ class SPADEBGenerator(BaseNetwork):
         x = self.G_middle_1(x, pyramid)
         for i, block in enumerate((self.up_0, self.up_1, self.up_2, self.up_3)):
             x = block(ops.upsample2x(x), pyramid)
+            last = i == 3
             if opt.bf_direct_add:
                 x = back_feats[i] + x
+                x = F.leaky_relu(x, 0.2) if last else x
             else:
-                x = ops.blend(back_feats[i], x, hair_masks[i], back_masks[i])
-        # conv_img(leaky_relu(x)) then tanh: the LeakyReLU is an elementwise pass, tanh is the conv epilogue
-        x = self.conv_img(F.leaky_relu(x, 0.2), act=ops.ACT_TANH)
+                # the LeakyReLU in front of conv_img (generator.py:227) rides on the last blend kernel
+                x = ops.blend(back_feats[i], x, hair_masks[i], back_masks[i], act=ops.ACT_LRELU if last else ops.ACT_NONE)
+        x = self.conv_img(x, act=ops.ACT_TANH)           # tanh is the conv epilogue
         return ops.to_nchw(x)

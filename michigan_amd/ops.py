@@ -340,11 +340,14 @@ class _SpadeFn(torch.autograd.Function):
         wp = pack_weight(w_gamma, w_beta, x.dtype, _roundup(rows, 128), actv.shape[3], 0)
         bias = _interleave32(b_gamma.detach().float(), b_beta.detach().float()).contiguous()
         out = torch.empty_like(x)
-        g1 = torch.empty_like(x)
+        # (1 + gamma) is only needed by the backward pass: the no_grad generator forward of the
+        # discriminator step (pix2pix_model.py:376) does not write it
+        g1 = torch.empty_like(x) if any(ctx.needs_input_grad) else None
         _launch_conv(actv, wp, out, bias, fwd_taps(kh, kh, kh // 2), Hj=h, Wj=w, isy=1, isx=1,
                      cout=c, cout_gemm=rows, act=act, slope=slope,
                      spade_x=x, mean=mean, rstd=rstd, gamma_out=g1)
-        ctx.save_for_backward(x, actv, w_gamma, w_beta, out, g1, mean, rstd)
+        if g1 is not None:
+            ctx.save_for_backward(x, actv, w_gamma, w_beta, out, g1, mean, rstd)
         ctx.cfg = (count, act, slope)
         return out
 
@@ -517,7 +520,7 @@ class _MaxPoolFn(torch.autograd.Function):
 
 class _BlendFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, bg, x, hair, back):
+    def forward(ctx, bg, x, hair, back, act, slope):
         bg, x = _nhwc(bg), _nhwc(x)
         if bg.shape != x.shape or bg.dtype != x.dtype:
             raise ValueError("blend: background features and x disagree")
@@ -527,21 +530,23 @@ class _BlendFn(torch.autograd.Function):
         if hair.numel() != n * h * w or back.numel() != n * h * w:
             raise ValueError("blend: masks must have one value per pixel")
         y = torch.empty_like(x)
-        C.backend().mg_blend_fwd(_p(bg), _p(x), _p(hair), _p(back), _p(y), _dt(x), n * h * w, c, _stream(x))
-        ctx.save_for_backward(hair, back)
+        C.backend().mg_blend_fwd(_p(bg), _p(x), _p(hair), _p(back), _p(y), _dt(x), n * h * w, c, act, slope, _stream(x))
+        ctx.save_for_backward(hair, back, y if act != ACT_NONE else None)
+        ctx.cfg = (act, slope)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        hair, back = ctx.saved_tensors
+        hair, back, y = ctx.saved_tensors
+        act, slope = ctx.cfg
         dy = dy.contiguous()
         c = dy.shape[-1]
         p = dy.numel() // c
         dbg = torch.empty_like(dy) if ctx.needs_input_grad[0] else None
         dx = torch.empty_like(dy) if ctx.needs_input_grad[1] else None
         if dbg is not None or dx is not None:
-            C.backend().mg_blend_bwd(_p(dy), _p(hair), _p(back), _p(dbg), _p(dx), _dt(dy), p, c, _stream(dy))
-        return dbg, dx, None, None
+            C.backend().mg_blend_bwd(_p(dy), _p(y), _p(hair), _p(back), _p(dbg), _p(dx), _dt(dy), p, c, act, slope, _stream(dy))
+        return dbg, dx, None, None, None, None
 
 
 def upsample2x(x):
@@ -559,9 +564,9 @@ def maxpool2(x):
     return _MaxPoolFn.apply(x)
 
 
-def blend(bg, x, hair_mask, back_mask):
-    """bg * (1 - hair_mask) + x * (1 - back_mask); masks are per-pixel (N*H*W values)."""
-    return _BlendFn.apply(bg, x, hair_mask, back_mask)
+def blend(bg, x, hair_mask, back_mask, *, act: int = ACT_NONE, slope: float = 0.2):
+    """act(bg * (1 - hair_mask) + x * (1 - back_mask)); masks are per-pixel (N*H*W values)."""
+    return _BlendFn.apply(bg, x, hair_mask, back_mask, act, slope)
 
 
 class _L1MeanFn(torch.autograd.Function):

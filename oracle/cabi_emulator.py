@@ -271,18 +271,20 @@ class EmulatorBackend:
         _view(dx, (N, H, W, C), td)[:] = full.to(td)
         return 0
 
-    def mg_blend_fwd(self, bg, x, hair, back, y, dtype, P, C, stream=None):
+    def mg_blend_fwd(self, bg, x, hair, back, y, dtype, P, C, act=0, slope=0.2, stream=None):
         td = _TD[dtype]
         b = _view(bg, (P, C), td).double()
         v = _view(x, (P, C), td).double()
         hm = _view(hair, (P, 1), torch.float32).double()
         bm = _view(back, (P, 1), torch.float32).double()
-        _view(y, (P, C), td)[:] = (b * (1 - hm) + v * (1 - bm)).to(td)
+        _view(y, (P, C), td)[:] = _act(b * (1 - hm) + v * (1 - bm), act, slope).to(td)
         return 0
 
-    def mg_blend_bwd(self, dy, hair, back, dbg, dx, dtype, P, C, stream=None):
+    def mg_blend_bwd(self, dy, y, hair, back, dbg, dx, dtype, P, C, act=0, slope=0.2, stream=None):
         td = _TD[dtype]
         d = _view(dy, (P, C), td).double()
+        if act != ACT_NONE:
+            d = d * _act_grad_from_out(_view(y, (P, C), td).double(), act, slope)
         hm = _view(hair, (P, 1), torch.float32).double()
         bm = _view(back, (P, 1), torch.float32).double()
         if _addr(dbg):

@@ -245,7 +245,7 @@ def test_blend_and_adam(dt):
     back = (torch.rand(2, 9, 9, 1, generator=g) > 0.5).float()
 
     def fn(bgf, x, hair, back):
-        y = ops.blend(bgf, x, hair, back)
+        y = ops.blend(bgf, x, hair, back, act=ops.ACT_LRELU)
         gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).to(y.dtype).to(y.device)
         return (y,) + torch.autograd.grad(y, (bgf, x), gy)
     (hip, _), (ref, _) = _both(fn, (bgf, x, hair, back))
