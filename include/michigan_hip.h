@@ -206,6 +206,16 @@ int mg_unpack_wgrad(const float* dw, float* d0, float* d1, int32_t cout, int32_t
 int mg_l1_mean_fwd(const void* a, const void* b, int32_t dtype, int64_t numel, float* out, float* partial, void* stream);
 int mg_l1_mean_bwd(const void* a, const void* b, const float* gscale, int32_t dtype, int64_t numel, void* da, void* stream);
 
+/* Orientation-loss filter bank (loss.py:274-313: 32 oriented 17x17 Gabor filters on the gray image, clamp at 0,
+ * max / arg-max over the 32 responses).  img is NHWC with C >= 3 (RGB in [-1,1] in channels 0..2); bank is
+ * fp32 [32][17][17]; conf[N][H][W] = max_k max(resp_k, 0), idx[N][H][W] = first arg-max (u8).  The contraction
+ * runs on the matrix cores in exact fp32.  bwd: dimg = adjoint of the winning-filter response w.r.t. the image
+ * (dconf must already be zero where conf == 0, i.e. where the clamp was active). */
+int mg_gabor_argmax_fwd(const void* img, const float* bank, float* conf, uint8_t* idx, int32_t dtype,
+                        int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int mg_gabor_argmax_bwd(const float* dconf, const uint8_t* idx, const float* bank, void* dimg, int32_t dtype,
+                        int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+
 /* Fused Adam over one flat fp32 parameter buffer (torch.optim.Adam semantics,
  * pix2pix_model.py:137-145: eps 1e-8, no weight decay, bias correction).
  * step is the 1-based step count. */

@@ -4,8 +4,8 @@
 run_discriminator_one_step` keep the reference's names and call structure
 (models/pix2pix_model.py:62-93,257-398, trainers/pix2pix_trainer.py:39-77) for the losses that
 sit on the hot path under the README flags:  hinge GAN (wide_edge), discriminator feature
-matching and VGG perceptual loss.  The orientation / Lab / style / background losses and the
-frozen in-painting net are outside this tier's scope and raise if enabled.
+matching, VGG perceptual loss and the Gabor orientation loss (on by default in the reference).  The Lab /
+style / background losses and the frozen in-painting net are outside this tier's scope.
 
 Differences that do not change results (SURVEY.md section 8a "parity-preserving minimum"):
   * the discriminator's parameters do not require grad during the generator step (their
@@ -39,6 +39,7 @@ def default_options(**over) -> argparse.Namespace:
         no_gan_loss=False, init_type="xavier", init_variance=0.02, remove_background=False, wide_edge=2.0,
         gan_mode="hinge", lambda_feat=1.0, lambda_vgg=1.0, lr=0.0002, beta1=0.5, beta2=0.999, no_TTUR=False,
         compute_dtype="bf16", curr_step=1, niter=50, niter_decay=0,
+        no_orient_loss=False, no_confidence_loss=True, lambda_orient=10.0, lambda_confidence=100.0, orient_filter="gabor",
     )
     d.update(over)
     return argparse.Namespace(**d)
@@ -58,6 +59,8 @@ class Pix2PixModel(nn.Module):
                 dt = getattr(opt, "compute_dtype", None)
                 if dt is not None:
                     self.criterionVGG.vgg.compute_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}.get(dt, dt)
+            if not getattr(opt, "no_orient_loss", True):
+                self.criterionOrient = networks.L1OLoss(opt)
 
     # -- data ---------------------------------------------------------------------
     def preprocess_input(self, data: Dict[str, torch.Tensor]):
@@ -116,6 +119,11 @@ class Pix2PixModel(nn.Module):
                 losses["GAN_Feat"] = self.criterionGANFeat(pred_fake, pred_real, label)
             if not self.opt.no_vgg_loss:
                 losses["VGG"] = self.criterionVGG(fake, d["image_tag"], label) * self.opt.lambda_vgg
+        if not getattr(self.opt, "no_orient_loss", True):
+            orient, conf = self.criterionOrient(fake, d["orient"], d["input_tag"])
+            losses["ORIENT"] = orient * self.opt.lambda_orient
+            if not self.opt.no_confidence_loss:
+                losses["CONFIDENCE"] = conf * self.opt.lambda_confidence
         return losses, fake
 
     def compute_discriminator_loss(self, d):

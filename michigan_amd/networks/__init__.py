@@ -17,14 +17,14 @@ from .base_network import BaseNetwork
 from .discriminator import MultiscaleDiscriminator, NLayerDiscriminator
 from .encoder import BackgroundEncode2, ConvBlock, ImageEncoder3, PartialConv2d
 from .generator import SPADEBGenerator
-from .loss import GANFeatLoss, GANLoss, VGGLoss
+from .loss import GANFeatLoss, GANLoss, L1OLoss, VGGLoss
 from .normalization import SPADE, SegPyramid, get_nonspade_norm_layer
 from .sync_batchnorm import DataParallelWithCallback, SynchronizedBatchNorm2d
 
 __all__ = [
     "BaseNetwork", "SPADEBGenerator", "MultiscaleDiscriminator", "NLayerDiscriminator", "SPADEResnetBlock",
     "SPADE", "SegPyramid", "VGG19", "ImageEncoder3", "BackgroundEncode2", "PartialConv2d", "ConvBlock",
-    "GANLoss", "GANFeatLoss", "VGGLoss", "SynchronizedBatchNorm2d", "DataParallelWithCallback",
+    "GANLoss", "GANFeatLoss", "VGGLoss", "L1OLoss", "SynchronizedBatchNorm2d", "DataParallelWithCallback",
     "get_nonspade_norm_layer", "find_network_using_name", "modify_commandline_options", "create_network",
     "define_G", "define_D",
 ]

@@ -6,6 +6,8 @@ discriminator feature matching, VGG perceptual loss); orientation / Lab / style 
 scope."""
 from __future__ import annotations
 
+import math
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -126,3 +128,35 @@ class VGGLoss(nn.Module):
             else:
                 loss = loss + w * ops.l1_mean(a, b)
         return loss
+
+
+class L1OLoss(nn.Module):
+    """Orientation loss (reference: loss.py:274-385, 'gabor' filter): the dominant orientation of the generated
+    image -- arg-max over 32 oriented Gabor responses of its gray version, weighted by a tanh confidence --
+    must match the orientation label inside the hair mask.  The filter bank, clamp, max and arg-max are one HIP
+    launch (ops.gabor_argmax); what remains here are a few passes over single-channel [N,H,W] maps."""
+
+    def __init__(self, opt, channel_in=1, channel_out=1, stride=1, padding=8):
+        super().__init__()
+        if getattr(opt, "orient_filter", "gabor") != "gabor":
+            raise NotImplementedError("orientation loss: only the (default) Gabor filter bank is implemented")
+        self.opt = opt
+        self.numKernels, self.kernel_size = 32, 17
+        self.register_buffer("bank", ops.gabor_bank(), persistent=False)
+
+    def forward(self, fake_image0, orientation_label0, input_semantics):
+        hair = input_semantics[:, 1:2].float()
+        img = fake_image0.permute(0, 2, 3, 1)                       # zero-copy for the generator's NHWC output
+        conf_raw, idx = ops.gabor_argmax(img, self.bank.to(img.device))
+        confidence = ((torch.tanh(conf_raw) + 1) / 2.0).unsqueeze(1)
+        ang = (idx.float() * (math.pi / self.numKernels)).unsqueeze(1)
+        orient_fake = torch.cat([torch.sin(2 * ang), torch.cos(2 * ang)], dim=1) * confidence
+        if not self.opt.use_ig:
+            lab = orientation_label0.float() / 255 * math.pi
+            orient_label = torch.cat([torch.sin(2 * lab), torch.cos(2 * lab)], dim=1)
+        else:
+            orient_label = orientation_label0.float()
+        orient_loss = F.l1_loss(orient_fake * hair, (orient_label * hair).detach())
+        conf = torch.clamp(confidence, 0.001, 1)
+        confidence_loss = -torch.sum(torch.log(conf) * hair) / torch.sum(hair)
+        return orient_loss, confidence_loss

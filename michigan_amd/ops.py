@@ -609,6 +609,51 @@ def l1_mean(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return _L1MeanFn.apply(a, b)
 
 
+def gabor_bank(device=None) -> torch.Tensor:
+    """The 32 oriented 17x17 Gabor kernels of the orientation loss, fp32 [32, 17, 17]
+    (loss.py:215-243: sigma_x 2, sigma_y 3, lambda 4, psi 0, theta_k = pi k / 32; x runs along rows)."""
+    import math
+    r = torch.arange(-8, 9, dtype=torch.float32)
+    x = r.view(-1, 1).expand(17, 17)
+    y = r.view(1, -1).expand(17, 17)
+    theta = (math.pi * torch.arange(32, dtype=torch.float32) / 32).view(-1, 1, 1)
+    xt = x * torch.cos(theta) + y * torch.sin(theta)
+    yt = -x * torch.sin(theta) + y * torch.cos(theta)
+    gb = torch.exp(-0.5 * (xt ** 2 / 2.0 ** 2 + yt ** 2 / 3.0 ** 2)) * torch.cos(2 * math.pi / 4.0 * xt)
+    return gb.contiguous().to(device) if device is not None else gb.contiguous()
+
+
+class _GaborMaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, bank):
+        img = _nhwc(img)
+        n, h, w, c = img.shape
+        conf = torch.empty((n, h, w), dtype=torch.float32, device=img.device)
+        idx = torch.empty((n, h, w), dtype=torch.uint8, device=img.device)
+        C.backend().mg_gabor_argmax_fwd(_p(img), _p(bank), _p(conf), _p(idx), _dt(img), n, h, w, c, _stream(img))
+        ctx.save_for_backward(conf, idx, bank)
+        ctx.meta = (img.dtype, c)
+        ctx.mark_non_differentiable(idx)
+        return conf, idx
+
+    @staticmethod
+    def backward(ctx, dconf, _didx):
+        conf, idx, bank = ctx.saved_tensors
+        dtype, c = ctx.meta
+        n, h, w = conf.shape
+        g = (dconf.float() * (conf > 0)).contiguous()                 # the clamp at 0 blocks the gradient
+        dimg = torch.empty((n, h, w, c), dtype=dtype, device=conf.device)
+        C.backend().mg_gabor_argmax_bwd(_p(g), _p(idx), _p(bank), _p(dimg), C.MG_BF16 if dtype == torch.bfloat16 else C.MG_F32,
+                                        n, h, w, c, _stream(conf))
+        return dimg, None
+
+
+def gabor_argmax(img_nhwc: torch.Tensor, bank: torch.Tensor):
+    """(max non-negative response, first arg-max) of the 32-filter Gabor bank on the gray image; differentiable
+    w.r.t. the image through the winning filter (what autograd does for the reference's max over channels)."""
+    return _GaborMaxFn.apply(img_nhwc, bank)
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, *, lr, beta1, beta2, eps, step, grad_scale=1.0):
     """In-place fused Adam on flat fp32 buffers (torch.optim.Adam semantics)."""
     for t in (param, grad, exp_avg, exp_avg_sq):

@@ -334,6 +334,34 @@ class EmulatorBackend:
         _view(da, (numel,), td)[:] = (torch.sign(av - bv) * g).to(td)
         return 0
 
+    @staticmethod
+    def _gray(img):
+        x = (img[..., :3].double() + 1) / 2 * 255
+        return 0.299 * x[..., 0] + 0.587 * x[..., 1] + 0.144 * x[..., 2]           # [N,H,W]
+
+    def mg_gabor_argmax_fwd(self, img, bank, conf, idx, dtype, N, H, W, C, stream=None):
+        import torch.nn.functional as F
+        g = self._gray(_view(img, (N, H, W, C), _TD[dtype]))[:, None]
+        k = _view(bank, (32, 1, 17, 17), torch.float32).double()
+        r = F.conv2d(g, k, padding=8).clamp_min(0)
+        _view(conf, (N, H, W), torch.float32)[:] = r.max(1)[0].float()
+        _view(idx, (N, H, W), torch.uint8)[:] = r.argmax(1).to(torch.uint8)
+        return 0
+
+    def mg_gabor_argmax_bwd(self, dconf, idx, bank, dimg, dtype, N, H, W, C, stream=None):
+        import torch.nn.functional as F
+        td = _TD[dtype]
+        g = _view(dconf, (N, H, W), torch.float32).double()
+        ix = _view(idx, (N, H, W), torch.uint8).long()
+        k = _view(bank, (32, 1, 17, 17), torch.float32).double()
+        onehot = torch.zeros((N, 32, H, W), dtype=torch.float64).scatter_(1, ix[:, None], g[:, None])
+        dgray = F.conv_transpose2d(onehot, k, padding=8)[:, 0]                       # adjoint of the correlation
+        out = _view(dimg, (N, H, W, C), td)
+        out.zero_()
+        for c, wgt in enumerate((0.299, 0.587, 0.144)):
+            out[..., c] = (dgray * wgt * 127.5).to(td)
+        return 0
+
     def mg_set_option(self, key, value):
         return 0
 

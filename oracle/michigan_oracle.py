@@ -327,3 +327,39 @@ def discriminate(sd_d: SD, input_tag, orient_in, fake, real, training=True, upda
     pf = [[t[: t.shape[0] // 2] for t in p] for p in out]
     pr = [[t[t.shape[0] // 2:] for t in p] for p in out]
     return pf, pr
+
+
+def gabor_bank():
+    """gabor_fn for the 32 orientations of L1OLoss, loss.py:215-243,288-293 (fp32 [32,1,17,17])."""
+    r = torch.arange(-8, 9).float()
+    y = r.view(1, -1).repeat(17, 1)
+    x = r.view(-1, 1).repeat(1, 17)
+    ks = []
+    for i in range(32):
+        theta = torch.tensor(math.pi * i / 32)
+        x_t = x * torch.cos(theta) + y * torch.sin(theta)
+        y_t = -x * torch.sin(theta) + y * torch.cos(theta)
+        ks.append(torch.exp(-.5 * (x_t ** 2 / 2.0 ** 2 + y_t ** 2 / 3.0 ** 2)) * torch.cos(2 * math.pi / 4.0 * x_t))
+    return torch.stack(ks)[:, None]
+
+
+def orientation_loss(fake_image, orientation_label, input_semantics, use_ig: bool = True):
+    """L1OLoss.forward with the Gabor bank, loss.py:352-385 (returns orient_loss, confidence_loss)."""
+    hair = input_semantics[:, 1:2]
+    img = (fake_image + 1) / 2.0 * 255
+    gray = (0.299 * img[:, 0] + 0.587 * img[:, 1] + 0.144 * img[:, 2]).unsqueeze(1)
+    res = F.conv2d(gray, gabor_bank().to(gray.dtype), padding=8)
+    res = torch.where(res < 0, torch.zeros_like(res), res)
+    idx = torch.argmax(res, dim=1).float()
+    conf = ((torch.tanh(torch.max(res, dim=1)[0]) + 1) / 2.0).unsqueeze(1)
+    ang = (idx * math.pi / 32).unsqueeze(1)
+    fake_o = torch.cat([torch.sin(2 * ang), torch.cos(2 * ang)], dim=1) * conf
+    if not use_ig:
+        lab = orientation_label / 255 * math.pi
+        label_o = torch.cat([torch.sin(2 * lab), torch.cos(2 * lab)], dim=1)
+    else:
+        label_o = orientation_label
+    orient_loss = F.l1_loss(fake_o * hair, (label_o * hair).detach())
+    conf_c = torch.clamp(conf, 0.001, 1)
+    confidence_loss = -torch.sum(torch.log(conf_c) * hair) / torch.sum(hair)
+    return orient_loss, confidence_loss

@@ -302,3 +302,36 @@ def test_l1_mean_fused(dt):
     _close(f"l1 {dt} grad", hip[1], ref[1], TOL[dt])
     want = torch.nn.functional.l1_loss(a.detach().float(), b.float()) * 3.0
     _close(f"l1 {dt} vs torch", hip[0], want.reshape(1), 1e-5)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_gabor_argmax_and_orientation_loss(dt):
+    """Filter-bank kernel vs its contract (values, arg-max agreement, image gradient) and the whole L1OLoss vs the oracle."""
+    import argparse
+    from michigan_amd import networks, ops
+    from michigan_amd.synth import synth_batch
+    from oracle import michigan_oracle as O
+    g = torch.Generator().manual_seed(21)
+    img = torch.tanh(torch.randn(2, 75, 83, 3, generator=g)).to(DT[dt]).requires_grad_()
+
+    def fn(img):
+        bank = ops.gabor_bank(img.device)
+        conf, idx = ops.gabor_argmax(img, bank)
+        gc = torch.rand(conf.shape, generator=torch.Generator().manual_seed(2)).to(conf.device)
+        (gi,) = torch.autograd.grad(conf, img, gc)
+        return conf, idx.float(), gi
+    (hip, _), (ref, _) = _both(fn, (img,))
+    _close(f"gabor conf {dt}", hip[0], ref[0], 1e-4)
+    agree = (hip[1].cpu() == ref[1].cpu()).float().mean().item()
+    assert agree > 0.999, f"arg-max agreement {agree}"
+    _close(f"gabor dimg {dt}", hip[2], ref[2], 5e-3 if dt == "f32" else 2e-2)
+
+    b = synth_batch(2, 96, seed=6)
+    fake = torch.tanh(torch.randn(2, 3, 96, 96, generator=g))
+    want_o, want_c = O.orientation_loss(fake, b["orient"], b["input_tag"], use_ig=True)
+    crit = networks.L1OLoss(argparse.Namespace(use_ig=True, orient_filter="gabor")).cuda()
+    f2 = fake.permute(0, 2, 3, 1).contiguous().to(DT[dt]).cuda()
+    got_o, got_c = crit(f2.permute(0, 3, 1, 2), b["orient"].cuda(), b["input_tag"].cuda())
+    tol = 1e-4 if dt == "f32" else 2e-2
+    assert abs(float(want_o) - float(got_o)) < tol * max(1.0, abs(float(want_o)))
+    assert abs(float(want_c) - float(got_c)) < tol * max(1.0, abs(float(want_c)))

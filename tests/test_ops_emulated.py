@@ -94,3 +94,29 @@ def test_flat_adam_matches_torch_adam(emulator_backend):
         ref.step()
     for p, q in zip(ps, qs):
         close(p.detach(), q.detach(), 1e-6)
+
+
+def test_orientation_loss_matches_oracle(emulator_backend):
+    """L1OLoss on the (emulated) Gabor arg-max kernel vs the oracle restatement, values and image gradient."""
+    import argparse
+    from michigan_amd import networks
+    from michigan_amd.synth import synth_batch
+    from oracle import michigan_oracle as O
+    b = synth_batch(2, 48, seed=6)
+    g = torch.Generator().manual_seed(9)
+    fake = torch.tanh(torch.randn(2, 3, 48, 48, generator=g))
+    f1 = fake.clone().requires_grad_()
+    want_o, want_c = O.orientation_loss(f1, b["orient"], b["input_tag"], use_ig=True)
+    (want_o * 10 + want_c * 0.5).backward()
+    crit = networks.L1OLoss(argparse.Namespace(use_ig=True, orient_filter="gabor"))
+    f2 = nhwc(fake).requires_grad_()                      # the generator hands over an NCHW view of NHWC memory
+    got_o, got_c = crit(f2.permute(0, 3, 1, 2), b["orient"], b["input_tag"])
+    (got_o * 10 + got_c * 0.5).backward()
+    assert abs(float(want_o) - float(got_o)) < 1e-5 and abs(float(want_c) - float(got_c)) < 1e-5
+    close(f2.grad.permute(0, 3, 1, 2), f1.grad, 1e-4)
+    close(ops_bank(), O.gabor_bank()[:, 0], 1e-6)
+
+
+def ops_bank():
+    from michigan_amd import ops
+    return ops.gabor_bank()

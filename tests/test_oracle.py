@@ -111,3 +111,16 @@ def test_state_dict_contract_fixture_is_current():
     opt = R.make_opt()
     assert {k: list(v.shape) for k, v in R.build_generator(opt).state_dict().items()} == contract["G"]
     assert {k: list(v.shape) for k, v in R.build_discriminator(opt).state_dict().items()} == contract["D"]
+
+
+@needs_ref
+def test_oracle_orientation_loss_matches_reference():
+    from michigan_amd.synth import synth_batch
+    L = R.losses()
+    b = synth_batch(2, 64, seed=3)
+    opt = R.make_opt(crop_size=64, orient_filter="gabor")
+    crit = L.L1OLoss(opt)
+    fake = torch.tanh(torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(4)))
+    want_o, want_c = crit(fake, b["orient"], b["input_tag"])
+    got_o, got_c = O.orientation_loss(fake, b["orient"], b["input_tag"], use_ig=True)
+    assert abs(float(want_o) - float(got_o)) < 1e-6 and abs(float(want_c) - float(got_c)) < 1e-5
