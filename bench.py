@@ -160,7 +160,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if a.dtype == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": (f"SPADEB G + multiscale PatchGAN D + VGG19 loss, full G step + D step (Adam), "
+            "config": {"workload": (f"SPADEB G + multiscale PatchGAN D + VGG19 + Gabor orientation losses, full G step + D step (Adam), "
                                     f"bs={a.batch_per_gpu}/GPU, {a.size}x{a.size}, BASELINE.json configs[2]") if a.mode == "train" else
                                    (f"SPADEB generator forward only (no_grad, train-mode BN), bs={a.batch_per_gpu}/GPU, "
                                     f"{a.size}x{a.size}, BASELINE.json configs[1]"),

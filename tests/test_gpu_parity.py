@@ -96,4 +96,4 @@ def test_train_step_runs_and_updates(hip_backend):
     tr.run_discriminator_one_step(data)
     assert all(torch.isfinite(v).all() for v in tr.d_losses.values()), tr.d_losses
     assert not torch.equal(d0, tr.optimizer_D.flat)
-    assert set(tr.get_latest_losses()) == {"GAN", "GAN_Feat", "VGG", "D_Fake", "D_real"}
+    assert set(tr.get_latest_losses()) == {"GAN", "GAN_Feat", "VGG", "ORIENT", "D_Fake", "D_real"}
