@@ -134,6 +134,13 @@ int64_t mg_stats_workspace(int32_t G, int64_t P, int32_t C);
 int mg_channel_stats(const void* x, int32_t dtype, int32_t G, int64_t P, int32_t C,
                      float* sums /* [G][2][C] */, void* partial, void* stream);
 
+/* sums[G][2][C] + element count -> mean[G][C], rstd[G][C] = 1/sqrt(biased_var + eps) (fp64 inside); when
+ * running_mean/var are given (G == 1) they are updated with momentum and the UNBIASED variance, as
+ * F.batch_norm does (sync_batchnorm/batchnorm.py:65-68,136-143).  `count` is the global element count
+ * (after the cross-rank all-reduce of `sums`). */
+int mg_norm_finalize(const float* sums, int32_t G, int32_t C, double count, float eps, float momentum,
+                     float* running_mean, float* running_var, float* mean, float* rstd, void* stream);
+
 /* y = act((x - mean[g][c]) * rstd[g][c])   (InstanceNorm2d + LeakyReLU,
  * discriminator.py:88-93, encoder.py:188-197) */
 int mg_norm_act_fwd(const void* x, void* y, int32_t dtype, int32_t G, int64_t P, int32_t C,

@@ -181,6 +181,28 @@ __global__ void norm_bwd_apply_kernel(const T* __restrict__ dh, const T* __restr
     }
 }
 
+// sums[g][2][C] (+ element count) -> mean / rstd (fp64 inside), optional running-statistics update (G == 1):
+// replaces a dozen [C]-sized eager ops per normalisation layer.
+__global__ void norm_finalize_kernel(const float* __restrict__ sums, int G, int C, double count, float eps, float momentum,
+                                     float* __restrict__ running_mean, float* __restrict__ running_var,
+                                     float* __restrict__ mean, float* __restrict__ rstd)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * C) return;
+    const int g = i / C, c = i - g * C;
+    const double s = sums[((size_t)g * 2) * C + c], ss = sums[((size_t)g * 2 + 1) * C + c];
+    const double m = s / count;
+    double var = ss / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
 static inline int ew_grid(int64_t n) { int64_t b = (n + NTHR - 1) / NTHR; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
 template <typename T, int MODE>
@@ -272,5 +294,19 @@ extern "C" int mg_norm_bwd_apply(const void* dh, const void* h, const void* x, c
                            (const float*)dh, (const float*)h, (const float*)x, (const float*)g1, (float*)dx,
                            nq, P, C, mean, rstd, s1, s2, act, slope);
     MG_CHECK_LAUNCH("mg_norm_bwd_apply");
+    return MG_OK;
+}
+
+extern "C" int mg_norm_finalize(const float* sums, int32_t G, int32_t C, double count, float eps, float momentum,
+                                float* running_mean, float* running_var, float* mean, float* rstd, void* stream)
+{
+    MG_CHECK_ARG(sums && mean && rstd, "mg_norm_finalize: null pointer");
+    MG_CHECK_ARG(G > 0 && C > 0 && count > 0, "mg_norm_finalize: bad geometry");
+    MG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr) && (running_mean == nullptr || G == 1),
+                 "mg_norm_finalize: running statistics need both buffers and G == 1");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3((G * C + 255) / 256), dim3(256), 0, st, sums, G, C, count, eps, momentum,
+                       running_mean, running_var, mean, rstd);
+    MG_CHECK_LAUNCH("mg_norm_finalize");
     return MG_OK;
 }

@@ -42,9 +42,10 @@ class SPADEResnetBlock(nn.Module):
             self.norm_s = SPADE(cfg, fin, label_nc)
 
     def forward(self, x, seg):
-        stats = ops.batch_stats(x) if self.training else None
-        x_s = self.conv_s(self.norm_s(x, seg, stats=stats)) if self.learned_shortcut else x
-        dx = self.conv_0(self.norm_0(x, seg, act=ops.ACT_LRELU, stats=stats))
+        h0, stats = self.norm_0(x, seg, act=ops.ACT_LRELU, return_stats=True)
+        shared = stats if self.training else None          # norm_s normalises the same x: reuse the reduction
+        x_s = self.conv_s(self.norm_s(x, seg, stats=shared)) if self.learned_shortcut else x
+        dx = self.conv_0(h0)
         return self.conv_1(self.norm_1(dx, seg, act=ops.ACT_LRELU), resid=x_s)
 
     def shortcut(self, x, seg):

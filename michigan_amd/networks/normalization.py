@@ -57,14 +57,16 @@ class SPADE(nn.Module):
         self.mlp_beta = HipConv2d(nhidden, norm_nc, kernel_size=ks, padding=pw)
         self.use_weight_norm = use_weight_norm
 
-    def forward(self, x, segmap, act=ops.ACT_NONE, stats=None):
+    def forward(self, x, segmap, act=ops.ACT_NONE, stats=None, return_stats=False):
         n, h, w, c = x.shape
         seg = segmap.at(h, w) if isinstance(segmap, SegPyramid) else SegPyramid(segmap, x.dtype).at(h, w)
-        mean, rstd, count = self.param_free_norm.statistics(x, stats)
+        st = self.param_free_norm.statistics(x, stats)
+        mean, rstd, count = st[0], st[1], st[2]
         actv = self.mlp_shared[0](seg, act=ops.ACT_RELU)
-        return ops.spade_modulate(x, actv, self.mlp_gamma.weight, self.mlp_gamma.bias,
-                                  self.mlp_beta.weight, self.mlp_beta.bias, mean, rstd, count,
-                                  act=act, slope=0.2)
+        out = ops.spade_modulate(x, actv, self.mlp_gamma.weight, self.mlp_gamma.bias,
+                                 self.mlp_beta.weight, self.mlp_beta.bias, mean, rstd, count,
+                                 act=act, slope=0.2)
+        return (out, st) if return_stats else out
 
 
 class _ConvNorm(nn.Sequential):

@@ -40,18 +40,21 @@ class SynchronizedBatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def statistics(self, x, precomputed=None):
+    def statistics(self, x, shared=None):
+        """shared = (mean, rstd, count, sums) already reduced by another layer normalising the same x
+        (SPADE norm_0 / norm_s): only this layer's running buffers still have to advance."""
         if not self.training:
             rstd = torch.rsqrt(self.running_var.float() + self.eps)
-            return self.running_mean.float().contiguous(), rstd.contiguous(), math.inf
-        mean, rstd, unbiased, count = precomputed if precomputed is not None else ops.batch_stats(x, self.eps)
+            return self.running_mean.float().contiguous(), rstd.contiguous(), math.inf, None
+        if shared is None:
+            return ops.batch_stats(x, self.eps, self.momentum, self.running_mean, self.running_var)
+        mean, rstd, count, sums = shared
         with torch.no_grad():
-            self.running_mean.mul_(1 - self.momentum).add_(mean, alpha=self.momentum)
-            self.running_var.mul_(1 - self.momentum).add_(unbiased, alpha=self.momentum)
-        return mean, rstd, count
+            ops.advance_running_stats(sums, count, self.eps, self.momentum, self.running_mean, self.running_var)
+        return mean, rstd, count, sums
 
     def forward(self, x):                                          # NHWC, stand-alone use
-        mean, rstd, _ = self.statistics(x)
+        mean, rstd, _, _ = self.statistics(x)
         y = (x.float() - mean) * rstd
         if self.affine:
             y = y * self.weight + self.bias

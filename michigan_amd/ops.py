@@ -288,33 +288,40 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 # ----------------------------------------------------------------------------
 # batch statistics (sync-BN) and SPADE modulation
 # ----------------------------------------------------------------------------
-def batch_stats(x: torch.Tensor, eps: float = 1e-5):
+def batch_stats(x: torch.Tensor, eps: float = 1e-5, momentum: float = 0.1,
+                running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None):
     """Per-channel batch statistics of an NHWC tensor over (N, H, W) [x all ranks of SYNC_BN_GROUP].
 
-    Returns (mean, rstd, unbiased_var, count); rstd = 1/sqrt(biased_var + eps) as F.batch_norm
-    computes it on one device (sync_batchnorm/batchnorm.py:65-68).  No autograd here: the
-    dependence of the statistics on x is handled inside the consumers' backward kernels.
+    Returns (mean, rstd, count); rstd = 1/sqrt(biased_var + eps) as F.batch_norm computes it on one device
+    (sync_batchnorm/batchnorm.py:65-68).  Three launches: two-stage channel sums, [one all-reduce of the 2C sums
+    when data parallel,] finalize (which also advances the running statistics when given).  Every rank holds the
+    same number of elements (equal per-GPU batch), so the global count is local count x world size -- no host
+    sync.  No autograd here: the dependence of the statistics on x is handled by the consumers' backward kernels.
     """
     with torch.no_grad():
         x = _nhwc(x)
         c = x.shape[-1]
         count = x.numel() // c
-        sums = channel_sums(x)[0].double()                     # [2, C]
+        sums = channel_sums(x)
         if SYNC_BN_GROUP is not None:
-            # ONE collective per layer: [sum | sum of squares | element count], fp64, no host sync --
-            # the global count stays a device scalar (ranks may hold different batch sizes).
             import torch.distributed as dist
-            packed = torch.cat([sums.reshape(-1), sums.new_tensor([float(count)])])
-            dist.all_reduce(packed, group=SYNC_BN_GROUP)
-            sums, count = packed[:-1].reshape(2, c), packed[-1]
-            denom = (count - 1).clamp_min(1.0)
-        else:
-            denom = max(count - 1, 1)
-        mean = sums[0] / count
-        var = (sums[1] / count - mean * mean).clamp_min_(0.0)
-        rstd = torch.rsqrt(var + eps)
-        unbiased = var * (count / denom)
-        return mean.float(), rstd.float(), unbiased.float(), count
+            dist.all_reduce(sums, group=SYNC_BN_GROUP)
+            count *= dist.get_world_size(SYNC_BN_GROUP)
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        C.backend().mg_norm_finalize(_p(sums), 1, c, float(count), eps, momentum, _p(running_mean), _p(running_var),
+                                     _p(mean), _p(rstd), _stream(x))
+        return mean, rstd, count, sums
+
+
+def advance_running_stats(sums: torch.Tensor, count, eps: float, momentum: float,
+                          running_mean: torch.Tensor, running_var: torch.Tensor):
+    """Apply the momentum update of ANOTHER norm layer that normalises the same tensor (SPADE norm_0 / norm_s share
+    x, architecture.py:68-70,79): one finalize launch on the already reduced sums."""
+    c = running_mean.numel()
+    scratch = torch.empty(2 * c, dtype=torch.float32, device=sums.device)
+    C.backend().mg_norm_finalize(_p(sums), 1, c, float(count), eps, momentum, _p(running_mean), _p(running_var),
+                                 _p(scratch[:c]), _p(scratch[c:]), _stream(sums))
 
 
 def _interleave32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -414,11 +421,10 @@ class _InstanceNormActFn(torch.autograd.Function):
         x = _nhwc(x)
         n, h, w, c = x.shape
         p = h * w
-        sums = channel_sums(x, groups=n).double()
-        mean = sums[:, 0] / p
-        var = (sums[:, 1] / p - mean * mean).clamp_min_(0.0)
-        rstd = torch.rsqrt(var + eps).float().contiguous()
-        mean = mean.float().contiguous()
+        sums = channel_sums(x, groups=n)
+        mean = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        C.backend().mg_norm_finalize(_p(sums), n, c, float(p), eps, 0.0, None, None, _p(mean), _p(rstd), _stream(x))
         y = torch.empty_like(x)
         C.backend().mg_norm_act_fwd(_p(x), _p(y), _dt(x), n, p, c, _p(mean), _p(rstd), act, slope, _stream(x))
         ctx.save_for_backward(x, y, mean, rstd)

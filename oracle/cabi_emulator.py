@@ -148,6 +148,18 @@ class EmulatorBackend:
         s[:, 1] = (xv * xv).sum(1).float()
         return 0
 
+    def mg_norm_finalize(self, sums, G, C, count, eps, momentum, running_mean, running_var, mean, rstd, stream=None):
+        s = _view(sums, (G, 2, C), torch.float32).double()
+        m = s[:, 0] / count
+        var = (s[:, 1] / count - m * m).clamp_min(0)
+        _view(mean, (G, C), torch.float32)[:] = m.float()
+        _view(rstd, (G, C), torch.float32)[:] = torch.rsqrt(var + eps).float()
+        if _addr(running_mean):
+            rm, rv = _view(running_mean, (C,), torch.float32), _view(running_var, (C,), torch.float32)
+            rm.mul_(1 - momentum).add_(m[0].float(), alpha=momentum)
+            rv.mul_(1 - momentum).add_((var[0] * (count / max(count - 1, 1))).float(), alpha=momentum)
+        return 0
+
     def mg_norm_act_fwd(self, x, y, dtype, G, P, C, mean, rstd, act, slope, stream=None):
         td = _TD[dtype]
         xv = _view(x, (G, P, C), td).double()

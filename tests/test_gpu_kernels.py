@@ -176,7 +176,7 @@ def test_spade_modulate_fwd_bwd(C, H, W, dt):
     bb = (torch.randn(C, generator=g) * 0.1).requires_grad_()
 
     def fn(x, actv, wg, bg, wb, bb):
-        mean, rstd, unb, cnt = ops.batch_stats(x)
+        mean, rstd, cnt, _ = ops.batch_stats(x)
         h = ops.spade_modulate(x, actv, wg, bg, wb, bb, mean, rstd, cnt, act=ops.ACT_LRELU)
         gh = torch.randn(h.shape, generator=torch.Generator().manual_seed(9)).to(h.dtype).to(h.device)
         grads = torch.autograd.grad(h, (x, actv, wg, bg, wb, bb), gh)

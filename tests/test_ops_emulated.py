@@ -49,7 +49,7 @@ def test_spade_modulate_matches_torch(emulator_backend, C):
     gh = torch.randn_like(h_ref)
     refs = torch.autograd.grad(h_ref, (x, actv, wg, bg, wb, bb), gh)
     xn, an = nhwc(x.detach()).requires_grad_(), nhwc(actv.detach()).requires_grad_()
-    mean, rstd, unb, cnt = ops.batch_stats(xn)
+    mean, rstd, cnt, _ = ops.batch_stats(xn)
     h = ops.spade_modulate(xn, an, wg, bg, wb, bb, mean, rstd, cnt, act=ops.ACT_LRELU)
     outs = torch.autograd.grad(h, (xn, an, wg, bg, wb, bb), nhwc(gh))
     close(h.permute(0, 3, 1, 2), h_ref)
@@ -57,7 +57,10 @@ def test_spade_modulate_matches_torch(emulator_backend, C):
     close(outs[1].permute(0, 3, 1, 2), refs[1])
     for o, r in zip(outs[2:], refs[2:]):
         close(o, r)
-    close(unb, x.detach().var(dim=(0, 2, 3), unbiased=True))
+    rm, rv = torch.zeros(C), torch.ones(C)
+    ops.batch_stats(xn.detach(), 1e-5, 0.1, rm, rv)
+    close(rv, 0.9 + 0.1 * x.detach().var(dim=(0, 2, 3), unbiased=True))
+    close(rm, 0.1 * x.detach().mean(dim=(0, 2, 3)))
 
 
 def test_instance_norm_and_resampling(emulator_backend):
