@@ -16,6 +16,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(64 << 20))   # see michigan_amd/__init__.py; before the first HIP call
+
 import torch
 import torch.distributed as dist
 

@@ -106,14 +106,34 @@ class Pix2PixModel(nn.Module):
         pred_real = [[t[half(t):] for t in p] for p in out]
         return pred_fake, pred_real
 
+    def _ref_is_tag_async(self, d):
+        """`sum(tag_mask - ref_mask) == 0` (pix2pix_model.py:286) evaluated on the device and copied to pinned host
+        memory without blocking; `_resolve_flag` waits only for that copy, so the host keeps enqueueing ahead of the GPU."""
+        flag = (d["input_tag"][:, 1] - d["input_ref"][:, 1]).sum() == 0
+        if not flag.is_cuda:
+            return flag, None
+        host = torch.empty((), dtype=torch.bool, pin_memory=True)
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return host, ev
+
+    @staticmethod
+    def _resolve_flag(pending):
+        host, ev = pending
+        if ev is not None:
+            ev.synchronize()
+        return bool(host)
+
     def compute_generator_loss(self, d):
         losses = {}
+        pending = self._ref_is_tag_async(d)
         fake = self.generate_fake(d)
         pred_fake, pred_real = self.discriminate(d, fake)
         label = d["input_tag"][:, 1:2]
         if not self.opt.no_gan_loss:
             losses["GAN"] = self.criterionGAN(pred_fake, True, for_discriminator=False, label=label)
-        ref_is_tag = bool((d["input_tag"][:, 1] - d["input_ref"][:, 1]).sum() == 0)
+        ref_is_tag = self._resolve_flag(pending)
         if self.opt.curr_step == 1 and ref_is_tag:
             if not self.opt.no_ganFeat_loss:
                 losses["GAN_Feat"] = self.criterionGANFeat(pred_fake, pred_real, label)

@@ -170,7 +170,8 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, kh: int, kw: int, stride: int
                     ids.append(ky * kw + kx)
             if not taps:
                 continue
-            wcls = wt if len(ids) == t else wt[ids].contiguous()
+            # (slices + cat, not wt[ids]: a Python index list is uploaded with a blocking host->device copy)
+            wcls = wt if len(ids) == t else torch.cat([wt[i:i + 1] for i in ids], dim=0)
             _launch_conv(dy, wcls, dx, None, taps, Hj=hj, Wj=wj, isy=1, isx=1,
                          osy=stride, osx=stride, ooy=py, oox=px, cout=cin, cout_gemm=cin)
     return dx
