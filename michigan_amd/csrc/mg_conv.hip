@@ -17,6 +17,7 @@
 
 int g_mg_conv_halo = 1;          // 3x3 stride-1 convs on the LDS halo-tile kernel (mg_set_option(2, v))
 int g_mg_conv_bigtiles = 1;      // allow the 128x256 / 256x256 tiles (mg_set_option(1, v))
+extern int g_mg_wgrad3x3;          // mg_wgrad.hip (mg_set_option(3, v))
 int g_mg_conv_pipeline = 1;      // 0 = register-staged double buffer, 1 = LDS-DMA 3-stage ring (mg_set_option(0, v))
 
 #include "mg_conv_common.h"
@@ -439,5 +440,6 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 0 && (value == 0 || value == 1)) { g_mg_conv_pipeline = value; return MG_OK; }
     if (key == 1 && (value == 0 || value == 1)) { g_mg_conv_bigtiles = value; return MG_OK; }
     if (key == 2 && (value == 0 || value == 1)) { g_mg_conv_halo = value; return MG_OK; }
+    if (key == 3 && (value == 0 || value == 1)) { g_mg_wgrad3x3 = value; return MG_OK; }
     return mg_fail(MG_ERR_ARG, "mg_set_option: unknown key/value %d/%d", key, value);
 }

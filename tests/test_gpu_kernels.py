@@ -163,6 +163,36 @@ def test_wgrad_bf16_both_fragment_paths(tr):
         ops.WGRAD_USE_TR = old
 
 
+# 3x3 / stride 1 / pad 1 weight gradient on the kernel-row workgroup kernel (mg_wgrad3x3.hip): every tile variant
+# (64/128 rows x 64/128 cols), W = 16 (two image rows per stage), 32 and 64, channel counts that are not tile
+# multiples, one and several splits, with and without the fused bias gradient.
+@pytest.mark.parametrize("want_bias", [False, True], ids=["nobias", "bias"])
+@pytest.mark.parametrize("N,H,W,cin,cg", [
+    (2, 16, 16, 128, 128), (1, 8, 32, 64, 256), (1, 6, 64, 128, 64), (2, 4, 16, 64, 64),
+    (1, 32, 32, 136, 200), (3, 16, 32, 72, 72), (1, 2, 16, 256, 128), (2, 64, 64, 128, 256)],
+    ids=lambda v: str(v))
+def test_wgrad3x3_kernel_row_tiles(N, H, W, cin, cg, want_bias):
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + cin)
+    x = torch.randn(N, H, W, cin, generator=g).bfloat16()
+    dy = torch.randn(N, H, W, cg, generator=g).bfloat16()
+
+    def fn(x, dy):
+        r = ops.conv_wgrad(x, dy, 3, 3, 1, 1, want_bias=want_bias)
+        return r if want_bias else (r,)
+    (hip, _), (ref, _) = _both(fn, (x, dy))
+    for name, a, r in zip(("dw", "dbias"), hip, ref):
+        _close(f"wgrad3x3 {(N, H, W, cin, cg)} {name}", a, r, 2e-3)
+    if not os.environ.get("MG_TEST_DRYRUN"):
+        from michigan_amd import _cabi
+        _cabi.backend().mg_set_option(3, 0)                       # same problem on the generic kernel
+        try:
+            gen = fn(x.cuda(), dy.cuda())
+        finally:
+            _cabi.backend().mg_set_option(3, 1)
+        _close(f"wgrad3x3 vs generic {(N, H, W, cin, cg)}", hip[0], gen[0].cpu(), 2e-3)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("C,H,W", [(64, 20, 24), (32, 16, 16), (48, 9, 11), (256, 8, 8), (16, 12, 12)])
 def test_spade_modulate_fwd_bwd(C, H, W, dt):
