@@ -15,6 +15,7 @@
 // pipe).  bf16 uses v_mfma_f32_32x32x16_bf16, f32 uses v_mfma_f32_32x32x2_f32
 // (exact fp32 fma chain) -- same tiling, same LDS image (64 B of K per row).
 
+int g_mg_conv_halo_big = 1;      // 128 channels x 16x16 pixel halo tiles where the launch is big enough (mg_set_option(4, v))
 int g_mg_conv_halo = 1;          // 3x3 stride-1 convs on the LDS halo-tile kernel (mg_set_option(2, v))
 int g_mg_conv_bigtiles = 1;      // allow the 128x256 / 256x256 tiles (mg_set_option(1, v))
 extern int g_mg_wgrad3x3;          // mg_wgrad.hip (mg_set_option(3, v))
@@ -441,5 +442,6 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 1 && (value == 0 || value == 1)) { g_mg_conv_bigtiles = value; return MG_OK; }
     if (key == 2 && (value == 0 || value == 1)) { g_mg_conv_halo = value; return MG_OK; }
     if (key == 3 && (value == 0 || value == 1)) { g_mg_wgrad3x3 = value; return MG_OK; }
+    if (key == 4 && (value == 0 || value == 1)) { g_mg_conv_halo_big = value; return MG_OK; }
     return mg_fail(MG_ERR_ARG, "mg_set_option: unknown key/value %d/%d", key, value);
 }

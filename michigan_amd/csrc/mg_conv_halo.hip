@@ -2,52 +2,76 @@
 //
 // The generic tap-list kernel re-fetches the activation tile once per tap (9x for a 3x3 conv): at
 // 128x128 tiles its operand stream (16 KiB per 1.05 MFLOP out of L2) is what bounds it at ~30 % MFMA
-// utilisation (profiles/r01_pmc_conv_spade_shape.txt).  Here a workgroup owns an 8x16 pixel rectangle of
-// one image and stages, per 64-byte channel chunk, its (8+2)x(16+2) input patch ONCE; the nine taps are
-// then nine shifted views of that patch in LDS (row = (py+1+dy)*18 + px+1+dx), so only the weights
-// (8 KiB per tap) keep streaming: 83.5 KiB instead of 144 KiB per chunk, and gamma/beta/conv weights of a
-// channel tile are reused across the whole rectangle.  SPADE's fused gamma/beta conv, conv_0/conv_1, the VGG
-// tower and their stride-1 dgrads all take this path (taps in {-1,0,1}^2, Cin a multiple of one chunk).
+// utilisation (profiles/r01_pmc_conv_spade_shape.txt).  Here a workgroup owns a TH x 16 pixel rectangle of
+// one image and stages, per 64-byte channel chunk, its (TH+2)x(16+2) input patch ONCE; the nine taps are
+// then nine shifted views of that patch in LDS, so only the weights keep streaming (one 4/8 KiB slab per
+// tap through a 3-slot ring).  SPADE's fused gamma/beta conv, conv_0/conv_1, the VGG tower and their
+// stride-1 dgrads all take this path (taps in {-1,0,1}^2, Cin a multiple of one chunk).
 //
-// LDS: weight ring 3 x 8 KiB (LDS-DMA, two taps in flight) + patch double buffer 2 x 12 KiB = 48 KiB ->
-// 3 workgroups per CU.  One s_barrier per tap; vmcnt immediates are static per tap position because the
-// nine taps of a chunk are fully unrolled.
+// Geometries (4 waves; a wave owns 64 channels x NT*32 pixels):
+//   <WM=2,NT=4> 128 channels x 16x16 pixels: the default.  The weight slabs are re-read by every workgroup, so
+//               they are the bulk of the L2->LDS stream (with 8x16 tiles 288 KiB of weights against 45 KiB of
+//               patch per workgroup at Cin = 128, ~10 TB/s over the chip, rocprofv3 TCP_TCC_READ_REQ); twice
+//               the pixels per workgroup halves that stream per FLOP and doubles the MFMA work per weight slab
+//               in flight.  128 accumulator registers -> 2 waves per SIMD, 72 KiB LDS -> 2 workgroups per CU.
+//   <WM=2,NT=2> 128 channels x  8x16 pixels: images with H < 16 and launches too small to fill the chip with
+//               the big tile.  48 KiB LDS -> 3 workgroups per CU.
+//   <WM=1,NT=2>  64 channels x 16x16 pixels: the 64-channel layers at 512^2 (up_3, VGG conv1_2).
+//
+// Pixel <-> lane map: MFMA column l (0..31) of a tile is pixel (row l >> 4, x = (l - 2*(l >> 4)) & 15): the odd
+// row is rotated by two pixels so that the 16 patch rows a ds_read_b128 lane group touches stay distinct
+// mod 16 (patch pitch 18 = 2 mod 16 made 1/3 of the LDS cycles bank conflicts, SQ_LDS_BANK_CONFLICT).
+//
+// Per tap the inner loop is 4 + 2*NT ds_read_b128 and 4*NT MFMAs; everything else is hoisted: the nine
+// swizzled patch addresses per column tile live in registers (the second K half is the first XOR 32 bytes),
+// weight addresses are a wave-uniform base (scalar registers, walked with scalar adds) plus a constant
+// per-lane offset (global_load_lds with an SGPR base), and one s_barrier + one vmcnt wait per tap.
 #include "mg_conv_common.h"
+
+extern int g_mg_conv_halo_big;     // mg_set_option(4, v): 0 = never use the 128 x 16x16 geometry
 
 namespace {
 
 constexpr int TW = 16, PW = TW + 2;
 
-// Two geometries (4 waves, each 64 channels x 64 pixels = 2x2 MFMA tiles):
-//   WM=2: 128 channels x  8x16 pixels, patch 10x18 = 180 rows (12 DMA blocks), weights 8 KiB per tap
-//   WM=1:  64 channels x 16x16 pixels, patch 18x18 = 324 rows (24 DMA blocks), weights 4 KiB per tap
-//          (the 64-channel layers at 512^2 -- up_3, VGG conv1_2 -- stage 3.2x fewer bytes per FLOP than on
-//          the generic 64x256 tile)
-template <int WM> struct HaloGeom {
+template <int WM, int NT> struct HaloGeom {
     static constexpr int WN = 4 / WM;
     static constexpr int TM = WM * 64;
-    static constexpr int TH = WN * 64 / TW;                    // 8 or 16
+    static constexpr int TH = WN * NT * 32 / TW;                // 8 or 16
     static constexpr int PROWS = (TH + 2) * PW;
-    static constexpr int PBLK = ((PROWS + 15) / 16 + 3) / 4 * 4;   // whole blocks per wave
+    static constexpr int PBLK = ((PROWS + 15) / 16 + 3) / 4 * 4;    // whole 16-row blocks, same count per wave
     static constexpr int PSTAGE = PBLK * 1024;
     static constexpr int ASTAGE = TM * ROWB;
     static constexpr int A_IPS = TM / 64, P_IPS = PBLK / 4;
     static constexpr int LDS = 3 * ASTAGE + 2 * PSTAGE;
+    static constexpr int OCC = NT == 4 ? 2 : 3;                 // waves per SIMD the register budget is set for
 };
 
-template <typename T, int EPI, int WM>
-__global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
+// global_load_lds with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst)
 {
-    using G = HaloGeom<WM>;
-    constexpr int MT = 2, NT = 2, WN = G::WN;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+template <typename T, int EPI, int WM, int NT>
+__global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(const ConvK d)
+{
+    using G = HaloGeom<WM, NT>;
+    constexpr int MT = 2, WN = G::WN;
     constexpr int TH = G::TH, PROWS = G::PROWS, PSTAGE = G::PSTAGE, ASTAGE = G::ASTAGE, TM_H = G::TM;
     constexpr int A_IPS = G::A_IPS, P_IPS = G::P_IPS;
+    constexpr bool BF = sizeof(T) == 2;
     constexpr int EPP = 16 / (int)sizeof(T);
     constexpr int CH  = ROWB / (int)sizeof(T);
+    constexpr int KX  = BF ? 32 : 16;                          // byte XOR that selects the lane's second K piece
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const ring = smem;
-    unsigned char* const patches = smem + 3 * ASTAGE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring 3 x ASTAGE][patch 2 x PSTAGE]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,7 +91,6 @@ __global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
     const int m0 = tm * TM_H, y0 = ty * TH, x0 = tx * TW;
 
     const T* __restrict__ In = reinterpret_cast<const T*>(d.in);
-    const T* __restrict__ Wt = reinterpret_cast<const T*>(d.wt);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
     const int lrow = lane >> 2;
@@ -84,14 +107,15 @@ __global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
         const bool ok = r < PROWS && (unsigned)iy < (unsigned)d.Hin && (unsigned)ix < (unsigned)d.Win;
         pp[j] = ok ? reinterpret_cast<const unsigned char*>(In + ((size_t)((img * d.Hin + iy) * d.Win + ix) * d.Cin + piece * EPP)) : zsrc;
     }
-    // weight source pointers for (tap 0, chunk 0)
-    const unsigned char* pa0[A_IPS];
+    // weights: wave-uniform walking base (the next (tap, chunk) slab to issue) + constant per-lane offsets
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(d.wt) + (size_t)m0 * d.Cin * sizeof(T);
+    unsigned woff[A_IPS];
 #pragma unroll
     for (int j = 0; j < A_IPS; ++j)
-        pa0[j] = reinterpret_cast<const unsigned char*>(Wt + ((size_t)(m0 + (wave + 4 * j) * 16 + lrow) * d.Cin + piece * EPP));
-    const size_t tapstride = (size_t)d.CoutP * d.Cin * sizeof(T);
+        woff[j] = (unsigned)(((wave + 4 * j) * 16 + lrow) * d.Cin + piece * EPP) * (unsigned)sizeof(T);
+    const long tapstride = (long)d.CoutP * d.Cin * (long)sizeof(T);
+    const long chunkwrap = (long)ROWB - 8 * tapstride;         // from (tap 8, chunk c) to (tap 0, chunk c + 1)
 
-    const int tapv = d.tap[lane];
     const int nchunk = d.Cin / CH;
 
     auto issue_patch = [&](int buf) {
@@ -102,12 +126,12 @@ __global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
             pp[j] += ROWB;
         }
     };
-    auto issue_a = [&](int slot, int tap, int chunk) {
+    auto issue_a = [&](int slot, bool last_tap) {
         const unsigned base = lds0 + slot * ASTAGE;
-        const size_t off = (size_t)tap * tapstride + (size_t)chunk * ROWB;
 #pragma unroll
         for (int j = 0; j < A_IPS; ++j)
-            glds16(pa0[j] + off, __builtin_amdgcn_readfirstlane(base + (wave + 4 * j) * 1024));
+            glds16_s(wbase, woff[j], __builtin_amdgcn_readfirstlane(base + (wave + 4 * j) * 1024));
+        wbase += last_tap ? chunkwrap : tapstride;
     };
 
     f32x16_t acc[MT][NT];
@@ -118,31 +142,39 @@ __global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    // lane's pixel inside the 8x16 rectangle, per MFMA column tile
-    int prow0[NT];
+    // LDS byte offsets (from smem) of this lane's operand pieces, K piece `ksp` (the other one is ^ KX):
+    //   A: row wm*64 + l31 (+32 per mt) of the slot;   B: per tap and column tile, the shifted patch pixel
+    const int ksp = BF ? hi : hi * 2;
+    const int aoff = (wm * 64 + l31) * ROWB + ((ksp ^ ((l31 >> 2) & 3)) << 4);
+    int boff[9][NT];
+    {
+        const int tapv = d.tap[lane];
+        const int py = l31 >> 4, px = (l31 - 2 * py) & 15;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int p = wn * 64 + nt * 32 + l31;
-        prow0[nt] = ((p >> 4) + 1) * PW + (p & 15) + 1;      // TW == 16
+        for (int t = 0; t < 9; ++t) {
+            const int tp = __builtin_amdgcn_readlane(tapv, t);
+            const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int brow = ((wn * NT + nt) * 2 + py + 1 + dy) * PW + px + 1 + dx;
+                boff[t][nt] = 3 * ASTAGE + brow * ROWB + ((ksp ^ ((brow >> 2) & 3)) << 4);
+            }
+        }
     }
-    const int swa = (l31 >> 2) & 3;
 
-    auto compute = [&](int slot, int buf, int dy, int dx) {
-        const unsigned char* As = ring + slot * ASTAGE + (wm * 64 + l31) * ROWB;
-        const unsigned char* Pb = patches + buf * PSTAGE;
-        int brow[NT], bsw[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { brow[nt] = prow0[nt] + dy * PW + dx; bsw[nt] = (brow[nt] >> 2) & 3; }
-        if constexpr (sizeof(T) == 2) {
+    auto compute = [&](auto t_, int slot) {
+        constexpr int t = decltype(t_)::value;
+        const unsigned char* As = smem + slot * ASTAGE;
+        if constexpr (BF) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8_t a[MT], b[NT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    a[mt] = *reinterpret_cast<const bf16x8_t*>(As + mt * 32 * ROWB + (((ks * 2 + hi) ^ swa) << 4));
+                    a[mt] = *reinterpret_cast<const bf16x8_t*>(As + mt * 32 * ROWB + (ks ? aoff ^ KX : aoff));
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    b[nt] = *reinterpret_cast<const bf16x8_t*>(Pb + brow[nt] * ROWB + (((ks * 2 + hi) ^ bsw[nt]) << 4));
+                    b[nt] = *reinterpret_cast<const bf16x8_t*>(smem + (ks ? boff[t][nt] ^ KX : boff[t][nt]));
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -153,13 +185,13 @@ __global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
             f32x4_t a[MT][2], b[NT][2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                a[mt][0] = *reinterpret_cast<const f32x4_t*>(As + mt * 32 * ROWB + (((hi * 2) ^ swa) << 4));
-                a[mt][1] = *reinterpret_cast<const f32x4_t*>(As + mt * 32 * ROWB + (((hi * 2 + 1) ^ swa) << 4));
+                a[mt][0] = *reinterpret_cast<const f32x4_t*>(As + mt * 32 * ROWB + aoff);
+                a[mt][1] = *reinterpret_cast<const f32x4_t*>(As + mt * 32 * ROWB + (aoff ^ KX));
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                b[nt][0] = *reinterpret_cast<const f32x4_t*>(Pb + brow[nt] * ROWB + (((hi * 2) ^ bsw[nt]) << 4));
-                b[nt][1] = *reinterpret_cast<const f32x4_t*>(Pb + brow[nt] * ROWB + (((hi * 2 + 1) ^ bsw[nt]) << 4));
+                b[nt][0] = *reinterpret_cast<const f32x4_t*>(smem + boff[t][nt]);
+                b[nt][1] = *reinterpret_cast<const f32x4_t*>(smem + (boff[t][nt] ^ KX));
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -174,30 +206,33 @@ __global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
 
     // prologue: patch of chunk 0, weights of taps 0 and 1
     issue_patch(0);
-    issue_a(0, 0, 0);
-    issue_a(1, 1, 0);
+    issue_a(0, false);
+    issue_a(1, false);
 
     for (int c = 0; c < nchunk; ++c) {
         const bool next_chunk = (c + 1 < nchunk);
+        const int pdelta = (c & 1) ? -PSTAGE : PSTAGE;          // this tap's patch addresses for the next chunk
         static_for<0, 9>([&](auto t_) {
             constexpr int t = decltype(t_)::value;
-            // loads younger than the weights of this tap: next tap's weights (2 per wave) and, right after
-            // a chunk started, the next chunk's patch (3 per wave) -- see the issue order below
+            // loads younger than the weights of this tap: next tap's weights (A_IPS per wave) and, right after
+            // a chunk started, the next chunk's patch (P_IPS per wave) -- see the issue order below
             if constexpr (t == 1 || t == 2) { if (next_chunk) wait_vmcnt<A_IPS + P_IPS>(); else wait_vmcnt<A_IPS>(); }
             else if constexpr (t == 8)      { if (next_chunk) wait_vmcnt<A_IPS>(); else wait_vmcnt<0>(); }
             else                            wait_vmcnt<A_IPS>();
             __builtin_amdgcn_s_barrier();
             // weights two taps ahead into the ring slot consumed at the previous tap
-            if constexpr (t < 7) issue_a((t + 2) % 3, t + 2, c);
-            else { if (next_chunk) issue_a((t + 2) % 3, t - 7, c + 1); }
+            if constexpr (t < 7) issue_a((t + 2) % 3, t == 6);
+            else { if (next_chunk) issue_a((t + 2) % 3, false); }
             if constexpr (t == 0) { if (next_chunk) issue_patch((c + 1) & 1); }
-            const int tp = __builtin_amdgcn_readlane(tapv, t);
-            compute(t % 3, c & 1, (int)(short)(tp & 0xffff), tp >> 16);
+            compute(t_, t % 3);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) boff[t][nt] += pdelta;
         });
     }
 
     auto pixmap = [&](int p, size_t& opix) -> bool {
-        const int y = y0 + (p >> 4), x = x0 + (p & 15);
+        const int py = p >> 4;
+        const int y = y0 + py, x = x0 + (((p & 15) - 2 * (py & 1)) & 15);
         if (y >= d.Hout || x >= d.Wout) return false;
         opix = (size_t)((img * d.Hout + y) * d.Wout + x);
         return true;
@@ -205,16 +240,21 @@ __global__ __launch_bounds__(NTHR) void conv3x3_halo_kernel(const ConvK d)
     conv_epilogue<T, MT, NT, EPI>(d, acc, m0, pixmap, wm, wn, l31, hi);
 }
 
-template <typename T, int EPI, int WM>
+template <typename T, int EPI, int WM, int NT>
 int launch_halo_g(ConvK& k, hipStream_t st)
 {
-    using G = HaloGeom<WM>;
+    using G = HaloGeom<WM, NT>;
     k.tiles_m = (k.Cout_gemm + G::TM - 1) / G::TM;
     k.tiles_y = (k.Hin + G::TH - 1) / G::TH;
     k.tiles_x = (k.Win + TW - 1) / TW;
     const long nblk = (long)k.N * k.tiles_y * k.tiles_x * k.tiles_m;
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_taps(halo): bad grid %ld", nblk);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, EPI, WM>), dim3((unsigned)nblk), dim3(NTHR), G::LDS, st, k);
+    auto kern = conv3x3_halo_kernel<T, EPI, WM, NT>;
+    if constexpr (G::LDS > 65536) {
+        static bool attr_done = false;
+        if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); attr_done = true; }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NTHR), G::LDS, st, k);
     MG_CHECK_LAUNCH("mg_conv_taps(halo)");
     return MG_OK;
 }
@@ -222,8 +262,11 @@ int launch_halo_g(ConvK& k, hipStream_t st)
 template <typename T, int EPI>
 int launch_halo(ConvK& k, hipStream_t st)
 {
-    if (k.Cout_gemm <= 64) return launch_halo_g<T, EPI, 1>(k, st);
-    return launch_halo_g<T, EPI, 2>(k, st);
+    if (k.Cout_gemm <= 64) return launch_halo_g<T, EPI, 1, 2>(k, st);
+    // 16x16-pixel tiles once they still give every CU its two workgroups at least twice over
+    const long big = (long)k.N * ((k.Hin + 15) / 16) * ((k.Win + 15) / 16) * ((k.Cout_gemm + 127) / 128);
+    if (g_mg_conv_halo_big && k.Hin >= 16 && big >= 1024) return launch_halo_g<T, EPI, 2, 4>(k, st);
+    return launch_halo_g<T, EPI, 2, 2>(k, st);
 }
 
 }  // namespace

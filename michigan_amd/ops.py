@@ -142,38 +142,55 @@ def unpack_wgrad(dw: torch.Tensor, shape, two: bool = False):
     return (d0, d1) if two else d0
 
 
+_DGRAD_CLASSES = {}     # (kh, kw, stride, pad) -> [(py, px, taps, (lo, hi))], tap order of the class-sorted weight image
+_DGRAD_PERM = {}        # (kh, kw, stride, pad, device) -> index tensor that sorts the packed taps by parity class
+
+
+def _dgrad_classes(kh: int, kw: int, stride: int, pad: int):
+    key = (kh, kw, stride, pad)
+    if key not in _DGRAD_CLASSES:
+        classes, order = [], []
+        for py in range(stride):
+            for px in range(stride):
+                taps, lo = [], len(order)
+                for ky in range(kh):
+                    if (py + pad - ky) % stride:
+                        continue
+                    for kx in range(kw):
+                        if (px + pad - kx) % stride:
+                            continue
+                        taps.append(((py + pad - ky) // stride, (px + pad - kx) // stride))
+                        order.append(ky * kw + kx)
+                classes.append((py, px, taps, (lo, len(order))))
+        _DGRAD_CLASSES[key] = (classes, order)
+    return _DGRAD_CLASSES[key]
+
+
 def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, kh: int, kw: int, stride: int, pad: int,
                in_hw: Tuple[int, int], cin: int) -> torch.Tensor:
     """Data gradient of a forward conv.  dy is [N, Ho, Wo, Cg8]; wt is the dgrad image
     [taps, roundup(cin,128), Cg8] (pack_weight mode 1).  For stride s the output pixels split into s*s
     parity classes; each class is a stride-1 gather over dy with the subset of taps whose offset is
-    divisible by s (no wasted MACs)."""
+    divisible by s (no wasted MACs).  The weight image is re-ordered once per call so that every class
+    reads a contiguous slice (one gather with a cached device index; a Python index list or per-class
+    copies would cost a blocking upload / a launch per class)."""
     n, ho, wo, cg8 = dy.shape
     t = kh * kw
     h, w = in_hw
     assert wt.shape[0] == t and wt.shape[2] == cg8
     dx = (torch.zeros if stride > 1 else torch.empty)((n, h, w, cin), dtype=dy.dtype, device=dy.device)
-    for py in range(stride):
-        hj = len(range(py, h, stride))
-        for px in range(stride):
-            wj = len(range(px, w, stride))
-            if hj == 0 or wj == 0:
-                continue
-            taps, ids = [], []
-            for ky in range(kh):
-                if (py + pad - ky) % stride:
-                    continue
-                for kx in range(kw):
-                    if (px + pad - kx) % stride:
-                        continue
-                    taps.append(((py + pad - ky) // stride, (px + pad - kx) // stride))
-                    ids.append(ky * kw + kx)
-            if not taps:
-                continue
-            # (slices + cat, not wt[ids]: a Python index list is uploaded with a blocking host->device copy)
-            wcls = wt if len(ids) == t else torch.cat([wt[i:i + 1] for i in ids], dim=0)
-            _launch_conv(dy, wcls, dx, None, taps, Hj=hj, Wj=wj, isy=1, isx=1,
-                         osy=stride, osx=stride, ooy=py, oox=px, cout=cin, cout_gemm=cin)
+    classes, order = _dgrad_classes(kh, kw, stride, pad)
+    if stride > 1:
+        pkey = (kh, kw, stride, pad, wt.device)
+        if pkey not in _DGRAD_PERM:
+            _DGRAD_PERM[pkey] = torch.tensor(order, dtype=torch.long, device=wt.device)
+        wt = wt.index_select(0, _DGRAD_PERM[pkey])
+    for py, px, taps, (lo, hi) in classes:
+        hj, wj = len(range(py, h, stride)), len(range(px, w, stride))
+        if hj == 0 or wj == 0 or not taps:
+            continue
+        _launch_conv(dy, wt[lo:hi], dx, None, taps, Hj=hj, Wj=wj, isy=1, isx=1,
+                     osy=stride, osx=stride, ooy=py, oox=px, cout=cin, cout_gemm=cin)
     return dx
 
 

@@ -16,7 +16,7 @@ for r in csv.DictReader(open(f[0])):
     k = r["Kernel_Name"][:70] + " grid=" + r.get("Grid_Size", "?")
     agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
-    if "conv_taps" in k or "wgrad" in k:
+    if "conv_taps" in k or "wgrad" in k or "halo" in k:
         print("$name", k, {c: round(sum(v) / len(v), 1) for c, v in d.items()}, "n=", len(next(iter(d.values()))))
 PY
 }
