@@ -26,7 +26,7 @@ int g_mg_conv_pipeline = 1;      // 0 = register-staged double buffer, 1 = LDS-D
 namespace {
 
 template <typename T, int WM, int WN, int MT, int NT, int EPI, bool PACK>
-__global__ __launch_bounds__(NTHR) void conv_taps_kernel(const ConvK d)
+__global__ __launch_bounds__(NTHR, 3) void conv_taps_kernel(const ConvK d)
 {
     constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
     constexpr int EPP = 16 / (int)sizeof(T);        // elements per 16-byte piece
@@ -133,6 +133,8 @@ __global__ __launch_bounds__(NTHR) void conv_taps_kernel(const ConvK d)
 
     // ---- main loop: double-buffered, one barrier per chunk -----------------
     int tap = 0, chunk = 0;
+    float* const par = reinterpret_cast<float*>(smem + 2 * STAGE);        // epilogue channel parameters
+    conv_stage_params<TM, EPI, NTHR>(d, m0, par, tid);
     gload(0, 0);
     lstore(0);
     __syncthreads();
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(NTHR) void conv_taps_kernel(const ConvK d)
         __syncthreads();
     }
 
-    conv_epilogue<T, MT, NT, EPI>(d, acc, m0, LinearPixMap{d, q0, HWj}, wm, wn, l31, hi);
+    conv_epilogue<T, MT, NT, EPI, TM>(d, acc, m0, LinearPixMap{d, q0, HWj}, wm, wn, l31, hi, par);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(NTHR) void conv_taps_kernel(const ConvK d)
 // fixed LDS budget the only way to feed the matrix pipe faster is more FLOP per staged byte: the
 // 256x256 tile needs half the bytes per FLOP of the 128x128 one.
 template <typename T, int WM, int WN, int MT, int NT, int EPI, bool PACK>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && MT * NT >= 8) ? 2 : 1) void conv_taps_glds_kernel(const ConvK d)
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (MT * NT >= 8 ? 2 : 3) : 1)) void conv_taps_glds_kernel(const ConvK d)
 {
     constexpr int NW = WM * WN;
     constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
@@ -278,6 +280,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && MT * NT >= 8) ? 2 : 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+    // epilogue channel parameters (LDS-DMA, the oldest loads of each wave; no ds_write in this kernel)
+    float* const par = reinterpret_cast<float*>(smem + NS * STAGE);
+    conv_stage_params_dma<TM, EPI, NW>(d, m0, lds0 + NS * STAGE, wave, lane);
     // prologue: the first NS-1 chunks in flight
     int tap = 0, chunk = 0;                 // position of the NEXT chunk to issue
     auto advance = [&]() { if (++chunk == nchunk) { chunk = 0; ++tap; } };
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && MT * NT >= 8) ? 2 : 
         islot = (islot == NS - 1) ? 0 : islot + 1;
     }
 
-    conv_epilogue<T, MT, NT, EPI>(d, acc, m0, LinearPixMap{d, q0, HWj}, wm, wn, l31, hi);
+    conv_epilogue<T, MT, NT, EPI, TM>(d, acc, m0, LinearPixMap{d, q0, HWj}, wm, wn, l31, hi, par);
 }
 
 template <typename T, int WM, int WN, int MT, int NT, int EPI, bool PACK>
@@ -331,7 +336,7 @@ int launch_conv_p(ConvK& k, hipStream_t st)
     if constexpr (TM % (16 * WM * WN) == 0) {
         if (g_mg_conv_pipeline == 1 || WM * WN != 4 || MT * NT > 4) {
             const size_t stage = (size_t)(TM + TN) * ROWB;
-            const size_t ldsr = (stage >= 32768 ? 4 : 3) * stage;
+            const size_t ldsr = (stage >= 32768 ? 4 : 3) * stage + 2 * TM * sizeof(float);
             auto kern = conv_taps_glds_kernel<T, WM, WN, MT, NT, EPI, PACK>;
             if (ldsr > 65536) {
                 static bool attr_done = false;       // raise the dynamic-LDS cap once per instantiation
@@ -343,7 +348,7 @@ int launch_conv_p(ConvK& k, hipStream_t st)
         }
     }
     if constexpr (WM * WN != 4 || MT * NT > 4) return mg_fail(MG_ERR_UNSUPPORTED, "mg_conv_taps: large tiles need the LDS-DMA pipeline");
-    const size_t lds = 2 * (size_t)(TM + TN) * ROWB;
+    const size_t lds = 2 * (size_t)(TM + TN) * ROWB + 2 * TM * sizeof(float);
     if constexpr (WM * WN == 4 && MT * NT <= 4) {
         hipLaunchKernelGGL((conv_taps_kernel<T, WM, WN, MT, NT, EPI, PACK>), dim3((unsigned)nblk), dim3(NTHR), lds, st, k);
         MG_CHECK_LAUNCH("mg_conv_taps");

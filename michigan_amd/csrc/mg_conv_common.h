@@ -5,6 +5,7 @@
 #include "mg_common.h"
 #include <type_traits>
 
+
 namespace {
 
 constexpr int ROWB = 64;    // bytes of K per LDS row and pipeline stage
@@ -89,12 +90,144 @@ __device__ __forceinline__ void static_for(F&& f)
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
+// Per-channel epilogue parameters of a workgroup's TM GEMM rows, staged once into LDS (2*TM floats at `par`):
+//   PLAIN: par[r] = bias[m0 + r] (0 where there is no bias / past Cout_gemm)
+//   SPADE: par[r] = bias[m0 + r] (interleaved gamma|beta rows), par[TM + c] = mean, par[TM + TM/2 + c] = rstd of
+//          output channel (m0 >> 1) + c
+// Call it BEFORE the first LDS-DMA load is issued (a ds_write issued while DMA loads were in flight left
+// DMA'd rows corrupted, tools/stress_conv.py) and before a barrier that precedes the epilogue (every K loop has one).
+template <int TM, int EPI, int NTHREADS>
+__device__ __forceinline__ void conv_stage_params(const ConvK& d, int m0, float* par, int tid)
+{
+    static_assert(TM <= NTHREADS && (TM & (TM - 1)) == 0, "one pass, every wave takes part");
+    {
+        const int r = tid & (TM - 1);                // waves past TM rewrite the same values: all waves run the same code
+        par[r] = (d.bias && m0 + r < d.Cout_gemm) ? d.bias[m0 + r] : 0.f;
+    }
+    if constexpr (EPI == MG_EPI_SPADE) {
+        {
+            const int c = tid & (TM / 2 - 1);
+            const int oc = (m0 >> 1) + c;
+            par[TM + c] = oc < d.Cout ? d.mean[oc] : 0.f;
+            par[TM + TM / 2 + c] = oc < d.Cout ? d.rstd[oc] : 0.f;
+        }
+    }
+}
+
+// branch-free activation for the batched epilogue: NONE / RELU / LRELU as one select (TANH takes the generic path)
+__device__ __forceinline__ float mg_act_fast(float v, float neg, bool relu)
+{
+    float r = v > 0.f ? v : v * neg;
+    return relu ? fmaxf(v, 0.f) : r;
+}
+
+// Batched epilogue (the common case: channel counts that are multiples of 4, no tanh).  Per-channel parameters
+// come from LDS (conv_stage_params); the only global loads left are the residual / SPADE x quads, issued as a
+// batch before their first use, so a workgroup pays one memory round trip per batch instead of one per
+// 4-channel group (the generic code below waits after every load; at 16-32 groups per lane that was longer than
+// the whole K loop of the 128-channel SPADE convs).  Addresses of non-existing pixels / channels are clamped
+// to a valid element and only the stores are predicated.  `wrow` = first GEMM row of the wave inside the tile.
+template <typename T, int MT, int NT, int EPI, int TM, typename PixMap>
+__device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&acc)[MT][NT], int m0, PixMap&& pixmap,
+                                                   int wm, int wn, int l31, int hi, const float* par)
+{
+    T* __restrict__ Out = reinterpret_cast<T*>(d.out);
+    const float neg = d.act == MG_ACT_NONE ? 1.f : (d.act == MG_ACT_RELU ? 0.f : d.slope);
+    const bool relu = d.act == MG_ACT_RELU;
+    size_t opix[NT];
+    bool pok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        pok[nt] = pixmap(wn * NT * 32 + nt * 32 + l31, opix[nt]);
+        opix[nt] = pok[nt] ? opix[nt] * d.Cout : 0;
+    }
+
+    if constexpr (EPI == MG_EPI_PLAIN) {
+        const T* __restrict__ Res = reinterpret_cast<const T*>(d.resid);
+        static_for<0, MT>([&](auto mt_) {
+            constexpr int mt = decltype(mt_)::value;
+            const int lr = wm * MT * 32 + mt * 32 + hi * 4;       // + rq*8: this lane's GEMM rows inside the tile
+            f32x4_t bias4[4];
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) bias4[rq] = *reinterpret_cast<const f32x4_t*>(par + lr + rq * 8);
+            static_for<0, NT>([&](auto nt_) {
+                constexpr int nt = decltype(nt_)::value;
+                f32x4_t rv[4];
+                if (Res) {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int co = m0 + lr + rq * 8;
+                        rv[rq] = ET<T>::load4(Res + opix[nt] + (co < d.Cout ? co : 0));
+                    }
+                }
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int co = m0 + lr + rq * 8;
+                    f32x4_t v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = acc[mt][nt][rq * 4 + j] + bias4[rq][j];
+                        if (Res) t += rv[rq][j];
+                        v[j] = mg_act_fast(t, neg, relu);
+                    }
+                    if (pok[nt] && co < d.Cout) ET<T>::store4(Out + opix[nt] + co, v);
+                }
+            });
+        });
+    } else {
+        // SPADE: acc[0] = gamma rows, acc[1] = beta rows of the same 32 output channels; two batches of 2 groups
+        const T* __restrict__ X = reinterpret_cast<const T*>(d.x);
+        T* __restrict__ G1 = reinterpret_cast<T*>(d.gamma_out);
+        const int lrow = wm * 64;                    // first GEMM row of this wave's [gamma|beta] block in the tile
+        static_for<0, 2>([&](auto h_) {
+            constexpr int h = decltype(h_)::value;
+            int oc[2];
+            f32x4_t xv[NT][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) oc[q] = ((m0 + lrow) >> 1) + (h * 2 + q) * 8 + hi * 4;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) xv[nt][q] = ET<T>::load4(X + opix[nt] + (oc[q] < d.Cout ? oc[q] : 0));
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int sub = (h * 2 + q) * 8 + hi * 4;
+                const f32x4_t bg = *reinterpret_cast<const f32x4_t*>(par + lrow + sub);
+                const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(par + lrow + 32 + sub);
+                const f32x4_t mean4 = *reinterpret_cast<const f32x4_t*>(par + TM + (lrow >> 1) + sub);
+                const f32x4_t rstd4 = *reinterpret_cast<const f32x4_t*>(par + TM + TM / 2 + (lrow >> 1) + sub);
+                static_for<0, NT>([&](auto nt_) {
+                    constexpr int nt = decltype(nt_)::value;
+                    const int rq = h * 2 + q;
+                    f32x4_t g, hv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        g[j] = 1.f + acc[0][nt][rq * 4 + j] + bg[j];
+                        const float bt = acc[1][nt][rq * 4 + j] + bb[j];
+                        const float xh = (xv[nt][q][j] - mean4[j]) * rstd4[j];
+                        hv[j] = mg_act_fast(xh * g[j] + bt, neg, relu);
+                    }
+                    if (pok[nt] && oc[q] < d.Cout) {
+                        const size_t o = opix[nt] + oc[q];
+                        ET<T>::store4(Out + o, hv);
+                        if (G1) ET<T>::store4(G1 + o, g);
+                    }
+                });
+            }
+        });
+    }
+}
+
 // `pixmap(p, opix)`: p = pixel index inside the workgroup's pixel tile (0 .. TN-1) -> false if the pixel does
 // not exist, else opix = flat output pixel index ((n*Hout + oy)*Wout + ox).
-template <typename T, int MT, int NT, int EPI, typename PixMap>
+template <typename T, int MT, int NT, int EPI, int TM, typename PixMap>
 __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT][NT], int m0, PixMap&& pixmap,
-                                              int wm, int wn, int l31, int hi)
+                                              int wm, int wn, int l31, int hi, const float* par)
 {
+    if (((d.Cout | d.Cout_gemm) & 3) == 0 && d.act != MG_ACT_TANH) {
+        conv_epilogue_fast<T, MT, NT, EPI, TM>(d, acc, m0, pixmap, wm, wn, l31, hi, par);
+        return;
+    }
     // ---- epilogue -----------------------------------------------------------
     T* __restrict__ Out = reinterpret_cast<T*>(d.out);
     // compile-time tile indices (static_for): runtime-indexed accumulator arrays would be demoted to scratch
@@ -191,6 +324,43 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
                  "global_load_lds_dwordx4 %1, off\n\t"
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst)      // 4 bytes per lane, lane i -> lds_dst + 4*i
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dword %1, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// conv_stage_params for the LDS-DMA kernels: the same 2*TM-float image, fetched with global_load_lds_dword so
+// that the kernel contains no ds_write at all.  (With a ds_write of these parameters in the prologue the halo
+// kernel produced rare wrong tiles -- tools/stress_conv.py, tests/test_gpu_kernels.py::test_conv_race_screen --
+// although every DMA'd byte was covered by a vmcnt wait and a barrier; without DS stores it is clean.)
+// Issue it before the prologue's operand loads: being the oldest loads of the wave, every later counted vmcnt
+// wait covers them.  `par_lds` is the LDS byte address of the image.
+template <int TM, int EPI, int NW>
+__device__ __forceinline__ void conv_stage_params_dma(const ConvK& d, int m0, unsigned par_lds, int wave, int lane)
+{
+    constexpr int NI = (EPI == MG_EPI_SPADE ? 2 * TM : TM) / 64;      // wave-instructions of 64 floats
+    const unsigned char* const z = g_mg_zeros + lane * 4;
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        if (k % NW != wave) continue;
+        const int i = k * 64 + lane;
+        const void* src = z;
+        if (i < TM) {
+            if (d.bias && m0 + i < d.Cout_gemm) src = d.bias + m0 + i;
+        } else {
+            const int c = (i - TM) % (TM / 2), oc = (m0 >> 1) + c;
+            if (oc < d.Cout) src = ((i - TM) < TM / 2 ? d.mean : d.rstd) + oc;
+        }
+        glds4(src, __builtin_amdgcn_readfirstlane(par_lds + k * 256));
+    }
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }

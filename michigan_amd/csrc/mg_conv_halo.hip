@@ -13,9 +13,9 @@
 //               they are the bulk of the L2->LDS stream (with 8x16 tiles 288 KiB of weights against 45 KiB of
 //               patch per workgroup at Cin = 128, ~10 TB/s over the chip, rocprofv3 TCP_TCC_READ_REQ); twice
 //               the pixels per workgroup halves that stream per FLOP and doubles the MFMA work per weight slab
-//               in flight.  128 accumulator registers -> 2 waves per SIMD, 72 KiB LDS -> 2 workgroups per CU.
+//               in flight.  128 accumulator registers -> 2 waves per SIMD, 73 KiB LDS -> 2 workgroups per CU.
 //   <WM=2,NT=2> 128 channels x  8x16 pixels: images with H < 16 and launches too small to fill the chip with
-//               the big tile.  48 KiB LDS -> 3 workgroups per CU.
+//               the big tile.  49 KiB LDS -> 3 workgroups per CU.
 //   <WM=1,NT=2>  64 channels x 16x16 pixels: the 64-channel layers at 512^2 (up_3, VGG conv1_2).
 //
 // Pixel <-> lane map: MFMA column l (0..31) of a tile is pixel (row l >> 4, x = (l - 2*(l >> 4)) & 15): the odd
@@ -43,7 +43,8 @@ template <int WM, int NT> struct HaloGeom {
     static constexpr int PSTAGE = PBLK * 1024;
     static constexpr int ASTAGE = TM * ROWB;
     static constexpr int A_IPS = TM / 64, P_IPS = PBLK / 4;
-    static constexpr int LDS = 3 * ASTAGE + 2 * PSTAGE;
+    static constexpr int PAR = 3 * ASTAGE + 2 * PSTAGE;          // epilogue channel parameters (2*TM floats)
+    static constexpr int LDS = PAR + 2 * TM * 4;
     static constexpr int OCC = NT == 4 ? 2 : 3;                 // waves per SIMD the register budget is set for
 };
 
@@ -204,6 +205,9 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
         }
     };
 
+    // epilogue channel parameters (LDS-DMA, the oldest loads of each wave)
+    float* const par = reinterpret_cast<float*>(smem + G::PAR);
+    conv_stage_params_dma<TM_H, EPI, 4>(d, m0, lds0 + G::PAR, wave, lane);
     // prologue: patch of chunk 0, weights of taps 0 and 1
     issue_patch(0);
     issue_a(0, false);
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
         opix = (size_t)((img * d.Hout + y) * d.Wout + x);
         return true;
     };
-    conv_epilogue<T, MT, NT, EPI>(d, acc, m0, pixmap, wm, wn, l31, hi);
+    conv_epilogue<T, MT, NT, EPI, TM_H>(d, acc, m0, pixmap, wm, wn, l31, hi, par);
 }
 
 template <typename T, int EPI, int WM, int NT>

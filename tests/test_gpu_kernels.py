@@ -316,6 +316,36 @@ def test_conv_matches_miopen_large_bf16():
     _close("linearity", y2, 2 * y, 2.0 ** -7)
 
 
+@pytest.mark.parametrize("variant,opts", [("halo16", {2: 1, 4: 1}), ("halo8", {2: 1, 4: 0}), ("generic", {2: 0, 4: 0})])
+@pytest.mark.parametrize("with_bias", [False, True], ids=["nobias", "bias"])
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_race_screen(variant, opts, with_bias, dt):
+    """The LDS-DMA pipelines order their loads with counted vmcnt + barriers only; a missing edge shows up as rare
+    wrong tiles that depend on timing.  40 repetitions of a chip-filling conv (8 x 256^2, 128 -> 128), each compared
+    with torch's fp32 conv: every run must agree (this caught the halo kernel going wrong ~10-90 % of the runs once a
+    ds_write of the epilogue parameters had been added to its prologue; they are staged by LDS-DMA since)."""
+    from michigan_amd import ops, _cabi
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(8, 256, 256, 128, generator=g).to(DT[dt]).cuda()
+    w = (torch.randn(128, 128, 3, 3, generator=g) / 34).cuda()
+    b = torch.randn(128, generator=g).cuda() if with_bias else None
+    wr = w if dt == "f32" else w.bfloat16().float()
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), wr, b, padding=1).permute(0, 2, 3, 1)
+    thr = 2e-3 if dt == "f32" else 0.06
+    be = _cabi.backend()
+    try:
+        for k, v in opts.items():
+            be.mg_set_option(k, v)
+        bad = 0
+        for _ in range(40):
+            y = ops.conv2d(x, w, b, padding=1).float()
+            bad += int(((y - ref).abs() > thr).sum() > 0)
+    finally:
+        be.mg_set_option(2, 1)
+        be.mg_set_option(4, 1)
+    assert bad == 0, f"{variant}: {bad} of 40 runs had wrong tiles"
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_l1_mean_fused(dt):
     from michigan_amd import ops
