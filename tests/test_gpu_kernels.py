@@ -193,6 +193,24 @@ def test_wgrad3x3_kernel_row_tiles(N, H, W, cin, cg, want_bias):
         _close(f"wgrad3x3 vs generic {(N, H, W, cin, cg)}", hip[0], gen[0].cpu(), 2e-3)
 
 
+def test_wgrad3x3_race_screen():
+    """Same screen for the weight-gradient LDS-DMA ring: 30 repetitions of a chip-filling problem, each against the
+    fp32 reference computed by torch (split-K atomics change the summation order, hence a tolerance, not equality)."""
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(8, 128, 128, 128, generator=g).bfloat16().cuda()
+    dy = torch.randn(8, 128, 128, 256, generator=g).bfloat16().cuda()
+    xf = torch.nn.functional.pad(x.float().permute(0, 3, 1, 2), (1, 1, 1, 1))
+    ref = torch.stack([torch.einsum("nchw,nkhw->kc", xf[:, :, ky:ky + 128, kx:kx + 128], dy.float().permute(0, 3, 1, 2))
+                       for ky in range(3) for kx in range(3)])                     # [9, Cg, Cin]
+    scale = ref.abs().max().item()
+    bad = 0
+    for _ in range(30):
+        dw = ops.conv_wgrad(x, dy, 3, 3, 1, 1)
+        bad += int((dw - ref).abs().max().item() > 2e-3 * scale)
+    assert bad == 0, f"{bad} of 30 runs differ from the reference"
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("C,H,W", [(64, 20, 24), (32, 16, 16), (48, 9, 11), (256, 8, 8), (16, 12, 12)])
 def test_spade_modulate_fwd_bwd(C, H, W, dt):

@@ -20,7 +20,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if r["Counter_Name"] != c: continue
         v = float(r["Counter_Value"]); s["all"] += v
         if "conv_taps" in r["Kernel_Name"] or "conv3x3_halo" in r["Kernel_Name"]: s["conv"] += v
-        if "wgrad_kernel" in r["Kernel_Name"]: s["wgrad"] += v
+        if "wgrad_kernel" in r["Kernel_Name"] or "wgrad3x3_kernel" in r["Kernel_Name"]: s["wgrad"] += v
     tot[c] = s
 steps = 2.0
 res = {k: {"fetch_kib_raw": tot["FETCH_SIZE"][k] / steps, "write_kib": tot["WRITE_SIZE"][k] / steps,
