@@ -104,6 +104,9 @@ class Pix2PixModel(nn.Module):
         half = lambda t: t.size(0) // 2
         pred_fake = [[t[:half(t)] for t in p] for p in out]
         pred_real = [[t[half(t):] for t in p] for p in out]
+        for pf, pr, p in zip(pred_fake, pred_real, out):          # the halves remember the stacked map they came from
+            for a, b, t in zip(pf, pr, p):                        # (GANFeatLoss computes on it directly)
+                a._mg_stacked = b._mg_stacked = t
         return pred_fake, pred_real
 
     def _ref_is_tag_async(self, d):

@@ -94,8 +94,13 @@ class GANFeatLoss(nn.Module):
         for i in range(num_d):
             for j in range(len(pred_fake[i]) - 1):
                 a, b = pred_fake[i][j], pred_real[i][j].detach()
+                stacked = getattr(a, "_mg_stacked", None)
+                if stacked is None or getattr(pred_real[i][j], "_mg_stacked", None) is not stacked:
+                    stacked = None
                 if getattr(self.opt, "remove_background", False):
                     val = self.L1_loss_mask(a.float(), b.float(), label.detach().float())
+                elif stacked is not None:
+                    val = ops.l1_mean_halves(stacked)             # fake and real are the two halves of one feature map
                 else:
                     val = ops.l1_mean(a, b)
                 total = total + val * self.opt.lambda_feat / num_d

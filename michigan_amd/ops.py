@@ -614,6 +614,42 @@ class _L1MeanFn(torch.autograd.Function):
         return da, None
 
 
+class _L1HalvesFn(torch.autograd.Function):
+    """mean |t[:B] - t[B:]| of a batch-stacked tensor (discriminator features of [fake | real]), gradient to the
+    first half only.  Same kernels as _L1MeanFn, but the gradient is produced in the STACKED layout (real half
+    zero): slicing the halves outside would make autograd materialise a zero-padded copy per feature map and add
+    it with a strided kernel."""
+
+    @staticmethod
+    def forward(ctx, t):
+        half = t.shape[0] // 2
+        a, b = t[:half], t[half:]
+        out = torch.empty(1, dtype=torch.float32, device=t.device)
+        ws = torch.empty(1024, dtype=torch.float32, device=t.device)
+        C.backend().mg_l1_mean_fwd(_p(a), _p(b), _dt(t), a.numel(), _p(out), _p(ws), _stream(t))
+        ctx.save_for_backward(t)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (t,) = ctx.saved_tensors
+        half = t.shape[0] // 2
+        g = g.reshape(1).float().contiguous()
+        dt = torch.empty_like(t)
+        C.backend().mg_l1_mean_bwd(_p(t[:half]), _p(t[half:]), _p(g), _dt(t), t[:half].numel(), _p(dt[:half]), _stream(t))
+        dt[half:].zero_()
+        return dt
+
+
+def l1_mean_halves(t: torch.Tensor) -> torch.Tensor:
+    """mean |t[:B] - t[B:].detach()| for a batch-stacked NCHW view of NHWC memory (or a dense tensor)."""
+    t = _dense_view(t)
+    half = t.shape[0] // 2
+    if t.shape[0] % 2 or t[:half].numel() % 4 or t.dtype not in (torch.float32, torch.bfloat16):
+        return F.l1_loss(t[:half].float(), t[half:].detach().float())
+    return _L1HalvesFn.apply(t)
+
+
 def _dense_view(t: torch.Tensor) -> torch.Tensor:
     """A contiguous alias of t when t is an NCHW view of NHWC memory (what the networks return), else a copy."""
     if t.dim() == 4:
