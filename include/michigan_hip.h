@@ -179,6 +179,11 @@ int mg_act_bwd(const void* dy, const void* y, void* dpre, int32_t dtype, int64_t
 int mg_upsample2x_fwd(const void* x, void* y, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int mg_upsample2x_bwd(const void* dy, void* dx, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 
+/* nn.ReflectionPad2d(P) on NHWC (MaskGAN_networks.py:114-121 ConvBlock(pad_type='reflect') as used by the
+ * background encoder, :96-103: pad 3 before the 7x7 conv, pad 1 before each 4x4 stride-2 conv) and its adjoint.  y is [N, H+2P, W+2P, C]. */
+int mg_reflect_pad_fwd(const void* x, void* y, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, void* stream);
+int mg_reflect_pad_bwd(const void* dy, void* dx, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, void* stream);
+
 /* F.avg_pool2d(k=3, s=2, p=1, count_include_pad=False) (discriminator.py:46-49) */
 int mg_avgpool3s2_fwd(const void* x, void* y, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int mg_avgpool3s2_bwd(const void* dy, void* dx, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);

@@ -58,6 +58,8 @@ _PROTOS = {
     "mg_act_bwd": ([_vp, _vp, _vp, _i32, _i64, _i32, _f32, _vp], _i32),
     "mg_upsample2x_fwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_upsample2x_bwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "mg_reflect_pad_fwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "mg_reflect_pad_bwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_avgpool3s2_fwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_avgpool3s2_bwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_maxpool2_fwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),

@@ -40,6 +40,49 @@ __global__ void up2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N
         ET<T>::store4(y + i * 4, ET<T>::load4(x + src));
     }
 }
+// nn.ReflectionPad2d(p): y[n, oy, ox, :] = x[n, refl(oy - p), refl(ox - p), :]   (one thread per OUTPUT quad)
+__device__ __forceinline__ int mg_reflect(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * n - 2 - i : i; }
+template <typename T>
+__global__ void reflect_pad_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int P)
+{
+    const int c4 = C / 4; const int Ho = H + 2 * P, Wo = W + 2 * P;
+    const int64_t n = (int64_t)N * Ho * Wo * c4;
+    GRID_STRIDE(i, n) {
+        const int qd = (int)(i % c4); int64_t p = i / c4;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho); const int b = (int)(p / Ho);
+        const size_t src = (((size_t)b * H + mg_reflect(oy - P, H)) * W + mg_reflect(ox - P, W)) * C + qd * 4;
+        ET<T>::store4(y + i * 4, ET<T>::load4(x + src));
+    }
+}
+// adjoint: dx[n, iy, ix, :] = sum of dy over the padded positions that read (iy, ix) -- itself plus, within P of a
+// border (excluding the border row/column itself), its mirror image on that side; up to 3 x 3 terms.
+template <typename T>
+__global__ void reflect_pad_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C, int P)
+{
+    const int c4 = C / 4; const int Ho = H + 2 * P, Wo = W + 2 * P;
+    const int64_t n = (int64_t)N * H * W * c4;
+    GRID_STRIDE(i, n) {
+        const int qd = (int)(i % c4); int64_t p = i / c4;
+        const int ix = (int)(p % W); p /= W;
+        const int iy = (int)(p % H); const int b = (int)(p / H);
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = iy + P;
+        if (iy >= 1 && iy <= P) ys[ny++] = P - iy;                         // mirrored above the top edge
+        if (iy <= H - 2 && iy >= H - 1 - P) ys[ny++] = P + 2 * (H - 1) - iy;   // mirrored below the bottom edge
+        xs[nx++] = ix + P;
+        if (ix >= 1 && ix <= P) xs[nx++] = P - ix;
+        if (ix <= W - 2 && ix >= W - 1 - P) xs[nx++] = P + 2 * (W - 1) - ix;
+        f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < ny; ++a)
+            for (int e = 0; e < nx; ++e) {
+                const f32x4_t v = ET<T>::load4(dy + (((size_t)b * Ho + ys[a]) * Wo + xs[e]) * C + qd * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] += v[j];
+            }
+        ET<T>::store4(dx + i * 4, o);
+    }
+}
 // dx[n,h,w,:] = sum of the 2x2 children of dy
 template <typename T>
 __global__ void up2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C)
@@ -340,6 +383,29 @@ extern "C" int mg_upsample2x_bwd(const void* dy, void* dx, int32_t dtype, int32_
     if (dtype == MG_BF16) hipLaunchKernelGGL(up2_bwd_kernel<uint16_t>, dim3(g), dim3(NTHR), 0, st, (const uint16_t*)dy, (uint16_t*)dx, N, H, W, C);
     else hipLaunchKernelGGL(up2_bwd_kernel<float>, dim3(g), dim3(NTHR), 0, st, (const float*)dy, (float*)dx, N, H, W, C);
     MG_CHECK_LAUNCH("mg_upsample2x_bwd");
+    return MG_OK;
+}
+
+extern "C" int mg_reflect_pad_fwd(const void* x, void* y, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, void* stream)
+{
+    MG_EW_GEOM("mg_reflect_pad_fwd"); MG_CHECK_ARG(x && y, "mg_reflect_pad_fwd: null pointer");
+    MG_CHECK_ARG(P >= 1 && P < H && P < W, "mg_reflect_pad_fwd: pad %d must be in [1, min(H, W))", P);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int g = ew_grid((int64_t)N * (H + 2 * P) * (W + 2 * P) * (C / 4));
+    if (dtype == MG_BF16) hipLaunchKernelGGL(reflect_pad_fwd_kernel<uint16_t>, dim3(g), dim3(NTHR), 0, st, (const uint16_t*)x, (uint16_t*)y, N, H, W, C, P);
+    else hipLaunchKernelGGL(reflect_pad_fwd_kernel<float>, dim3(g), dim3(NTHR), 0, st, (const float*)x, (float*)y, N, H, W, C, P);
+    MG_CHECK_LAUNCH("mg_reflect_pad_fwd");
+    return MG_OK;
+}
+extern "C" int mg_reflect_pad_bwd(const void* dy, void* dx, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t P, void* stream)
+{
+    MG_EW_GEOM("mg_reflect_pad_bwd"); MG_CHECK_ARG(dy && dx, "mg_reflect_pad_bwd: null pointer");
+    MG_CHECK_ARG(P >= 1 && P < H && P < W, "mg_reflect_pad_bwd: pad %d must be in [1, min(H, W))", P);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int g = ew_grid((int64_t)N * H * W * (C / 4));
+    if (dtype == MG_BF16) hipLaunchKernelGGL(reflect_pad_bwd_kernel<uint16_t>, dim3(g), dim3(NTHR), 0, st, (const uint16_t*)dy, (uint16_t*)dx, N, H, W, C, P);
+    else hipLaunchKernelGGL(reflect_pad_bwd_kernel<float>, dim3(g), dim3(NTHR), 0, st, (const float*)dy, (float*)dx, N, H, W, C, P);
+    MG_CHECK_LAUNCH("mg_reflect_pad_bwd");
     return MG_OK;
 }
 

@@ -50,11 +50,14 @@ class HipInstanceNorm2d(nn.Module):
 
 
 def reflect_pad_nhwc(x: torch.Tensor, p: int) -> torch.Tensor:
-    """nn.ReflectionPad2d(p) on an NHWC tensor (slices + flips: differentiable, stays NHWC)."""
+    """nn.ReflectionPad2d(p) on an NHWC tensor (one HIP gather pass each way; the slice/flip/cat form copied the
+    tensor twice forward and added strided pieces backward)."""
     if p == 0:
         return x
-    x = torch.cat([x[:, 1:p + 1].flip(1), x, x[:, -p - 1:-1].flip(1)], dim=1)
-    return torch.cat([x[:, :, 1:p + 1].flip(2), x, x[:, :, -p - 1:-1].flip(2)], dim=2)
+    if x.shape[-1] % 4:                                      # odd channel counts: differentiable torch form
+        x = torch.cat([x[:, 1:p + 1].flip(1), x, x[:, -p - 1:-1].flip(1)], dim=1)
+        return torch.cat([x[:, :, 1:p + 1].flip(2), x, x[:, :, -p - 1:-1].flip(2)], dim=2)
+    return ops.reflect_pad(x, p)
 
 
 def nearest_resize_nchw(t: torch.Tensor, size) -> torch.Tensor:

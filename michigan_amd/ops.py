@@ -573,6 +573,34 @@ class _BlendFn(torch.autograd.Function):
         return dbg, dx, None, None, None, None
 
 
+class _ReflectPadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        x = _nhwc(x)
+        n, h, w, c = x.shape
+        y = torch.empty((n, h + 2 * p, w + 2 * p, c), dtype=x.dtype, device=x.device)
+        C.backend().mg_reflect_pad_fwd(_p(x), _p(y), _dt(x), n, h, w, c, p, _stream(x))
+        ctx.meta = (n, h, w, c, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, h, w, c, p = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty((n, h, w, c), dtype=dy.dtype, device=dy.device)
+        C.backend().mg_reflect_pad_bwd(_p(dy), _p(dx), _dt(dy), n, h, w, c, p, _stream(dy))
+        return dx, None
+
+
+def reflect_pad(x: torch.Tensor, p: int) -> torch.Tensor:
+    """nn.ReflectionPad2d(p) on an NHWC tensor: one gather pass forward, one gather pass (adjoint) backward."""
+    if p == 0:
+        return x
+    if x.shape[-1] % 4 or not (1 <= p < min(x.shape[1], x.shape[2])):
+        raise ValueError("reflect_pad: channels must be a multiple of 4 and 1 <= p < min(H, W)")
+    return _ReflectPadFn.apply(x, p)
+
+
 def upsample2x(x):
     """nn.Upsample(scale_factor=2, mode='nearest') on NHWC."""
     return _Up2Fn.apply(x)

@@ -224,6 +224,23 @@ class EmulatorBackend:
         _view(dx, (N, H, W, C), td)[:] = d.sum((2, 4)).to(td)
         return 0
 
+    def mg_reflect_pad_fwd(self, x, y, dtype, N, H, W, C, P, stream=None):
+        td = _TD[dtype]
+        xv = _view(x, (N, H, W, C), td).permute(0, 3, 1, 2)
+        out = torch.nn.functional.pad(xv.double(), (P, P, P, P), mode="reflect").permute(0, 2, 3, 1)
+        _view(y, (N, H + 2 * P, W + 2 * P, C), td)[:] = out.to(td)
+        return 0
+
+    def mg_reflect_pad_bwd(self, dy, dx, dtype, N, H, W, C, P, stream=None):
+        td = _TD[dtype]
+        d = _view(dy, (N, H + 2 * P, W + 2 * P, C), td).double()
+        iy = (torch.arange(-P, H + P).abs()); iy = torch.where(iy >= H, 2 * H - 2 - iy, iy)
+        ix = (torch.arange(-P, W + P).abs()); ix = torch.where(ix >= W, 2 * W - 2 - ix, ix)
+        acc = torch.zeros(N, H, W + 2 * P, C, dtype=torch.float64).index_add_(1, iy, d)
+        out = torch.zeros(N, H, W, C, dtype=torch.float64).index_add_(2, ix, acc)
+        _view(dx, (N, H, W, C), td)[:] = out.to(td)
+        return 0
+
     @staticmethod
     def _pool_cnt(L, Lo):
         o = torch.arange(Lo)

@@ -365,6 +365,25 @@ def test_conv_race_screen(variant, opts, with_bias, dt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,H,W,C,P", [(2, 9, 11, 8, 3), (1, 16, 16, 64, 1), (2, 5, 7, 12, 2), (1, 4, 4, 8, 3)])
+def test_reflect_pad_fwd_bwd(N, H, W, C, P, dt):
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(H * 100 + W)
+    x = torch.randn(N, H, W, C, generator=g).to(DT[dt]).requires_grad_()
+
+    def fn(x):
+        y = ops.reflect_pad(x, P)
+        gy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(y.dtype).to(y.device)
+        (gx,) = torch.autograd.grad(y, x, gy)
+        return y, gx
+    (hip, _), (ref, _) = _both(fn, (x,))
+    _close(f"reflect pad y {dt}", hip[0], ref[0], 0.0 if dt == "f32" else TOL[dt])
+    _close(f"reflect pad dx {dt}", hip[1], ref[1], TOL[dt])
+    want = torch.nn.functional.pad(x.detach().float().permute(0, 3, 1, 2), (P, P, P, P), mode="reflect").permute(0, 2, 3, 1)
+    _close("reflect pad vs torch", hip[0], want, 0.0 if dt == "f32" else TOL[dt])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_l1_mean_fused(dt):
     from michigan_amd import ops
     g = torch.Generator().manual_seed(12)
