@@ -199,7 +199,19 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int,
     want_bias=True also returns the bias gradient [Cg8] (column sums of dy) from the same launch."""
     n, h, w, cin = x.shape
     _, hj, wj, cg8 = dy.shape
-    taps = fwd_taps(kh, kw, pad)
+    if stride == 1 and cg8 <= 8 and cin >= 32:
+        # Few output channels (conv_img, the discriminators' 1-channel heads): a 128-row tile would be 94 % padding.
+        # dW[t][co][ci] = sum_q x[q][ci] * dy[q + (pad - k_t)][co] is the weight gradient of the mirrored problem with
+        # the roles of x and dy swapped, whose tiny "Cin" takes the packed-taps path; transpose the small result.
+        swapped = _wgrad_launch(dy, x, [(pad - ky, pad - kx) for ky in range(kh) for kx in range(kw)], 1, False)
+        dw = swapped.transpose(1, 2).contiguous()
+        return (dw, channel_sums(dy)[0, 0].contiguous()) if want_bias else dw
+    return _wgrad_launch(x, dy, fwd_taps(kh, kw, pad), stride, want_bias)
+
+
+def _wgrad_launch(x, dy, taps, stride, want_bias):
+    n, h, w, cin = x.shape
+    _, hj, wj, cg8 = dy.shape
     dw = torch.zeros((len(taps), cg8, cin), dtype=torch.float32, device=x.device)
     dbias = torch.zeros(cg8, dtype=torch.float32, device=x.device) if want_bias else None
     d = C.WgradDesc()
