@@ -22,6 +22,8 @@ from __future__ import annotations
 import ctypes
 from typing import List, Optional, Sequence, Tuple
 
+import weakref
+
 import torch
 import torch.nn.functional as F
 
@@ -122,7 +124,27 @@ def _launch_conv(inp, wt, out, bias, taps, *, Hj, Wj, isy, isx, osy=1, osx=1, oo
 def pack_weight(w0: torch.Tensor, w1: Optional[torch.Tensor], dtype, rows_p: int, cols_p: int, mode: int) -> torch.Tensor:
     """Reference-layout fp32 weight(s) [Cout, Cin, kh, kw] -> GEMM image [taps, rows_p, cols_p] in `dtype`
     (one HIP launch: permute + zero-pad + cast; two tensors = fused SPADE gamma/beta row interleave).
-    mode 0: rows = output channels (forward / wgrad image); mode 1: rows = input channels (dgrad image)."""
+    mode 0: rows = output channels (forward / wgrad image); mode 1: rows = input channels (dgrad image).
+    Images of frozen leaf weights (the VGG tower: requires_grad False, no autograd history) are cached per tensor
+    version, so the tower's weights are packed once instead of on each of its three passes per step."""
+    key = None
+    if w1 is None and not w0.requires_grad and w0.grad_fn is None and w0.is_leaf:
+        key = (w0.data_ptr(), w0._version, dtype, rows_p, cols_p, mode, tuple(w0.shape))
+        hit = _PACK_CACHE.get(key)
+        if hit is not None and hit[0]() is w0:
+            return hit[1]
+    dst = _pack_weight(w0, w1, dtype, rows_p, cols_p, mode)
+    if key is not None:
+        if len(_PACK_CACHE) > 256:
+            _PACK_CACHE.clear()
+        _PACK_CACHE[key] = (weakref.ref(w0), dst)
+    return dst
+
+
+_PACK_CACHE = {}
+
+
+def _pack_weight(w0, w1, dtype, rows_p, cols_p, mode):
     w0 = w0.detach().float().contiguous()
     if w1 is not None:
         w1 = w1.detach().float().contiguous()
@@ -178,8 +200,10 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, kh: int, kw: int, stride: int
     t = kh * kw
     h, w = in_hw
     assert wt.shape[0] == t and wt.shape[2] == cg8
-    dx = (torch.zeros if stride > 1 else torch.empty)((n, h, w, cin), dtype=dy.dtype, device=dy.device)
     classes, order = _dgrad_classes(kh, kw, stride, pad)
+    # the s*s parity classes partition the input pixels; only a class without taps (kernel smaller than the stride) leaves holes
+    full = all(taps for _, _, taps, _ in classes)
+    dx = (torch.empty if full else torch.zeros)((n, h, w, cin), dtype=dy.dtype, device=dy.device)
     if stride > 1:
         pkey = (kh, kw, stride, pad, wt.device)
         if pkey not in _DGRAD_PERM:
