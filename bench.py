@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--mode", default="train", choices=["train", "gfwd"],
                     help="train = G step + D step (headline); gfwd = BASELINE configs[1]: generator forward only, no_grad, train-mode BN")
+    ap.add_argument("--inpaint-orient", action="store_true",
+                    help="also run the frozen orientation in-painting net in both phases (BASELINE configs[4], --use_ig)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -98,7 +100,7 @@ def main():
     assert _cabi.backend().name == "hip"
 
     torch.manual_seed(0)
-    opt = default_options(crop_size=a.size, gpu_ids=[local], compute_dtype=a.dtype)
+    opt = default_options(crop_size=a.size, gpu_ids=[local], compute_dtype=a.dtype, inpaint_orient=a.inpaint_orient)
     trainer = Pix2PixTrainer(opt)
     data = {k: v.cuda() for k, v in synth_batch(a.batch_per_gpu, a.size, seed=1234 + rank).items()}
 
@@ -163,7 +165,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if a.dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": (f"SPADEB G + multiscale PatchGAN D + VGG19 + Gabor orientation losses, full G step + D step (Adam), "
-                                    f"bs={a.batch_per_gpu}/GPU, {a.size}x{a.size}, BASELINE.json configs[2]") if a.mode == "train" else
+                                    f"bs={a.batch_per_gpu}/GPU, {a.size}x{a.size}, BASELINE.json configs[2]"
+                                    + (" + frozen orientation in-painting net in both phases (configs[4] --use_ig)" if a.inpaint_orient else "")) if a.mode == "train" else
                                    (f"SPADEB generator forward only (no_grad, train-mode BN), bs={a.batch_per_gpu}/GPU, "
                                     f"{a.size}x{a.size}, BASELINE.json configs[1]"),
                        "global_batch": gbatch, "batch_per_gpu": a.batch_per_gpu, "resolution": a.size,

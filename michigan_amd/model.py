@@ -40,6 +40,9 @@ def default_options(**over) -> argparse.Namespace:
         gan_mode="hinge", lambda_feat=1.0, lambda_vgg=1.0, lr=0.0002, beta1=0.5, beta2=0.999, no_TTUR=False,
         compute_dtype="bf16", curr_step=1, niter=50, niter_decay=0,
         no_orient_loss=False, no_confidence_loss=True, lambda_orient=10.0, lambda_confidence=100.0, orient_filter="gabor",
+        # run the frozen in-painting net on (hole, orient_rgb, noise) like the reference does under --use_ig
+        # (pix2pix_model.py:260-263); off by default: BASELINE configs[1-3] feed the orientation map directly
+        netIG="inpaint", inpaint_orient=False,
     )
     d.update(over)
     return argparse.Namespace(**d)
@@ -61,6 +64,11 @@ class Pix2PixModel(nn.Module):
                     self.criterionVGG.vgg.compute_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}.get(dt, dt)
             if not getattr(opt, "no_orient_loss", True):
                 self.criterionOrient = networks.L1OLoss(opt)
+        self.netIG = None
+        if getattr(opt, "inpaint_orient", False):
+            self.netIG = networks.define_IG(opt).eval()          # frozen (pix2pix_model.py:196-198)
+            for p in self.netIG.parameters():
+                p.requires_grad_(False)
 
     # -- data ---------------------------------------------------------------------
     def preprocess_input(self, data: Dict[str, torch.Tensor]):
@@ -68,7 +76,7 @@ class Pix2PixModel(nn.Module):
         or already one-hot maps (michigan_amd.synth.synth_batch)."""
         dev = next(self.netG.parameters()).device
         out = {}
-        for k in ("input_tag", "input_ref", "image_tag", "image_ref", "orient", "noise"):
+        for k in ("input_tag", "input_ref", "image_tag", "image_ref", "orient", "noise", "hole", "orient_rgb"):
             if k in data:
                 out[k] = data[k].to(dev, non_blocking=True)
         for src, dst in (("label_tag", "input_tag"), ("label_ref", "input_ref")):
@@ -84,6 +92,29 @@ class Pix2PixModel(nn.Module):
             ang = o / 255.0 * math.pi
             return torch.cat([torch.sin(2 * ang), torch.cos(2 * ang)], dim=1) * d["input_tag"][:, 1:2]
         return o
+
+    def inpainting_orient(self, hole, orient_rgb, noise, mask):
+        """pix2pix_model.py:407-429: fill the hole of the RGB-coded orientation map with the frozen net (always at
+        256x256, nearest resampling either way) and return (RGB map in [0,1], 2-channel orientation x mask)."""
+        import torch.nn.functional as F
+        inp = torch.cat([orient_rgb * (1 - hole) + noise * hole, hole], dim=1)
+        if self.opt.crop_size != 256:
+            inp = F.interpolate(inp, size=(256, 256), mode="nearest")
+        out = self.netIG(inp)
+        if self.opt.crop_size != 256:
+            out = F.interpolate(out, size=(self.opt.crop_size, self.opt.crop_size), mode="nearest")
+        out = out * hole + orient_rgb * (1 - hole)
+        o2 = (out[:, :-1] - 0.5) * 2
+        return out, torch.stack([o2[:, 1], o2[:, 0]], dim=1) * mask
+
+    def _maybe_inpaint(self, d):
+        if self.netIG is None:
+            return d
+        with torch.no_grad():
+            _, orient = self.inpainting_orient(d["hole"], d["orient_rgb"], d["noise"], d["input_tag"][:, 1:2])
+        d = dict(d)
+        d["orient"] = orient.detach()
+        return d
 
     # -- networks -------------------------------------------------------------------
     def generate_fake(self, d):
@@ -130,6 +161,7 @@ class Pix2PixModel(nn.Module):
 
     def compute_generator_loss(self, d):
         losses = {}
+        d = self._maybe_inpaint(d)
         pending = self._ref_is_tag_async(d)
         fake = self.generate_fake(d)
         pred_fake, pred_real = self.discriminate(d, fake)
@@ -150,6 +182,7 @@ class Pix2PixModel(nn.Module):
         return losses, fake
 
     def compute_discriminator_loss(self, d):
+        d = self._maybe_inpaint(d)
         with torch.no_grad():
             fake = self.generate_fake(d)
         fake = fake.detach()
@@ -166,7 +199,7 @@ class Pix2PixModel(nn.Module):
             return self.compute_discriminator_loss(d)
         if mode == "inference":
             with torch.no_grad():
-                return self.generate_fake(d)
+                return self.generate_fake(self._maybe_inpaint(d))
         raise ValueError("|mode| is invalid")
 
     def create_optimizers(self, opt, group=None):
@@ -191,6 +224,8 @@ class Pix2PixTrainer:
         if group is not None:
             parallel.broadcast_parameters(self.pix2pix_model.netG)
             parallel.broadcast_parameters(self.pix2pix_model.netD)
+            if self.pix2pix_model.netIG is not None:
+                parallel.broadcast_parameters(self.pix2pix_model.netIG)
         self.optimizer_G, self.optimizer_D = self.pix2pix_model.create_optimizers(opt, group)
         self.old_lr = opt.lr
         self.g_losses, self.d_losses, self.generated = {}, {}, None

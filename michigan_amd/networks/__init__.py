@@ -17,6 +17,7 @@ from .base_network import BaseNetwork
 from .discriminator import MultiscaleDiscriminator, NLayerDiscriminator
 from .encoder import BackgroundEncode2, ConvBlock, ImageEncoder3, PartialConv2d
 from .generator import SPADEBGenerator
+from .inpaint import InpaintGenerator
 from .loss import GANFeatLoss, GANLoss, L1OLoss, VGGLoss
 from .normalization import SPADE, SegPyramid, get_nonspade_norm_layer
 from .sync_batchnorm import DataParallelWithCallback, SynchronizedBatchNorm2d
@@ -26,7 +27,7 @@ __all__ = [
     "SPADE", "SegPyramid", "VGG19", "ImageEncoder3", "BackgroundEncode2", "PartialConv2d", "ConvBlock",
     "GANLoss", "GANFeatLoss", "VGGLoss", "L1OLoss", "SynchronizedBatchNorm2d", "DataParallelWithCallback",
     "get_nonspade_norm_layer", "find_network_using_name", "modify_commandline_options", "create_network",
-    "define_G", "define_D",
+    "define_G", "define_D", "define_IG", "InpaintGenerator",
 ]
 
 
@@ -76,3 +77,8 @@ def define_G(opt):
 
 def define_D(opt):
     return create_network(find_network_using_name(opt.netD, "discriminator"), opt)
+
+
+def define_IG(opt):
+    """The frozen orientation in-painting generator (`--use_ig`, models/networks/__init__.py:70-72)."""
+    return create_network(find_network_using_name(getattr(opt, "netIG", "inpaint"), "generator"), opt)

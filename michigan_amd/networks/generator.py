@@ -93,3 +93,8 @@ class SPADEBGenerator(BaseNetwork):
                 x = ops.blend(back_feats[i], x, hair_masks[i], back_masks[i], act=ops.ACT_LRELU if last else ops.ACT_NONE)
         x = self.conv_img(x, act=ops.ACT_TANH)           # tanh is the conv epilogue
         return ops.to_nchw(x)
+
+
+# `--netIG inpaint` resolves through find_network_using_name(opt.netIG, "generator") exactly like the reference
+# (models/networks/__init__.py:70-72), so the class has to be visible in this module's namespace.
+from .inpaint import InpaintGenerator  # noqa: E402,F401

@@ -1,0 +1,108 @@
+"""The frozen orientation in-painting network (`--use_ig`): inference only.
+
+Reference: models/networks/generator.py:450-575 (`ResnetBlock`, `SelfAttention`, `InpaintGenerator`, skips=False) and
+its caller models/pix2pix_model.py:407-429.  Parameters, buffers and nn.Sequential indices are the reference's, so its
+`InpaintingModel_gen.pth` checkpoints load unchanged.  The network runs at 256x256 without gradients:
+7x7 / 4x4-stride-2 / dilated 3x3 / transposed 4x4 convolutions on the MFMA tap-list kernels (the transposed ones as
+per-parity-class gathers), InstanceNorm(+ReLU/LeakyReLU) on the fused norm kernels, reflection padding on the gather
+kernel; the 4096x4096 self-attention is two batched GEMMs + a softmax (rocBLAS through torch.bmm).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .base_network import BaseNetwork
+from .layers import HipConv2d
+
+
+class InferConv2d(nn.Conv2d):
+    """nn.Conv2d parameters, inference-only forward (any dilation) on NHWC."""
+
+    def forward(self, x, act=ops.ACT_NONE, slope=0.2):
+        if self.padding_mode != "zeros" or self.groups != 1 or self.kernel_size[0] != self.kernel_size[1]:
+            raise NotImplementedError("InferConv2d: zero padding, groups 1, square kernels only")
+        return ops.conv2d_infer(x, self.weight, self.bias, stride=self.stride[0], padding=self.padding[0],
+                                dilation=self.dilation[0], act=act, slope=slope)
+
+
+class InferConvTranspose2d(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d parameters ([Cin, Cout, k, k]; spectral_norm picks dim=1 for this class, as in the
+    reference), inference-only forward on NHWC."""
+
+    def forward(self, x):
+        if self.output_padding != (0, 0) or self.groups != 1 or self.dilation != (1, 1):
+            raise NotImplementedError("InferConvTranspose2d: no output padding / groups / dilation")
+        return ops.conv_transpose2d_infer(x, self.weight, self.bias, stride=self.stride[0], padding=self.padding[0])
+
+
+def _sn(m):
+    return nn.utils.spectral_norm(m)
+
+
+class ResnetBlock(nn.Module):
+    """x + IN(conv3x3(reflpad1(relu(IN(conv3x3_dil2(reflpad2(x)))))))  (generator.py:450-464)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.conv_block = nn.Sequential(
+            nn.ReflectionPad2d(2), _sn(InferConv2d(dim, dim, 3, stride=1, padding=0, dilation=2)), nn.InstanceNorm2d(dim),
+            nn.ReLU(True), nn.ReflectionPad2d(1), _sn(InferConv2d(dim, dim, 3, stride=1, padding=0)), nn.InstanceNorm2d(dim))
+
+    def forward(self, x):                                   # NHWC
+        cb = self.conv_block
+        y = cb[1](ops.reflect_pad(x, 2))
+        y = ops.instance_norm_act(y, act=ops.ACT_RELU)
+        y = cb[5](ops.reflect_pad(y, 1))
+        return x + ops.instance_norm_act(y, act=ops.ACT_NONE)
+
+
+class SelfAttention(nn.Module):
+    """cat([x, V softmax(Q^T K)^T]) over the H*W positions (generator.py:467-486); 1x1 projections on the conv kernels."""
+
+    def __init__(self, dim, downsample=4):
+        super().__init__()
+        self.query_conv = InferConv2d(dim, dim // downsample, 1)
+        self.key_conv = InferConv2d(dim, dim // downsample, 1)
+        self.value_conv = InferConv2d(dim, dim, 1)
+        self.softmax = nn.Softmax(dim=-1)
+
+    def forward(self, x):                                   # NHWC
+        n, h, w, c = x.shape
+        q = self.query_conv(x).reshape(n, h * w, -1).float()
+        k = self.key_conv(x).reshape(n, h * w, -1).float()
+        v = self.value_conv(x).reshape(n, h * w, c).float()
+        attn = torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1)       # [n, HW, HW]
+        out = torch.bmm(attn, v).reshape(n, h, w, c).to(x.dtype)
+        return torch.cat([x, out], dim=3)
+
+
+class InpaintGenerator(BaseNetwork):
+    def __init__(self, opt, blocks=12, skips=False):
+        super().__init__()
+        if skips:
+            raise NotImplementedError("InpaintGenerator: the skip-connection variant is not used by the reference's options")
+        self.skips = skips
+        self.encoder = nn.Sequential(
+            nn.ReflectionPad2d(3), _sn(InferConv2d(4, 64, 7, padding=0)), nn.InstanceNorm2d(64), nn.LeakyReLU(0.2, True),
+            _sn(InferConv2d(64, 128, 4, stride=2, padding=1)), nn.InstanceNorm2d(128), nn.LeakyReLU(0.2, True),
+            _sn(InferConv2d(128, 256, 4, stride=2, padding=1)), nn.InstanceNorm2d(256), nn.LeakyReLU(0.2, True))
+        self.middle = nn.Sequential(*[ResnetBlock(256) for _ in range(blocks)], SelfAttention(256))
+        self.decoder = nn.Sequential(
+            _sn(InferConvTranspose2d(512, 128, 4, stride=2, padding=1)), nn.InstanceNorm2d(128), nn.ReLU(True),
+            _sn(InferConvTranspose2d(128, 64, 4, stride=2, padding=1)), nn.InstanceNorm2d(64), nn.ReLU(True),
+            nn.ReflectionPad2d(3), InferConv2d(64, 3, 7, padding=0))
+
+    @torch.no_grad()
+    def forward(self, x):                                   # NCHW [N, 4, H, W] -> NCHW [N, 3, H, W] in [0, 1]
+        e, d = self.encoder, self.decoder
+        y = ops.pad_channels(ops.to_nhwc(x, self.compute_dtype), 8)
+        y = ops.instance_norm_act(e[1](ops.reflect_pad(y, 3)), act=ops.ACT_LRELU, slope=0.2)
+        y = ops.instance_norm_act(e[4](y), act=ops.ACT_LRELU, slope=0.2)
+        y = ops.instance_norm_act(e[7](y), act=ops.ACT_LRELU, slope=0.2)
+        y = self.middle(y)
+        y = ops.instance_norm_act(d[0](y), act=ops.ACT_RELU)
+        y = ops.instance_norm_act(d[3](y), act=ops.ACT_RELU)
+        y = d[7](ops.reflect_pad(y, 3), act=ops.ACT_TANH)
+        return (ops.to_nchw(y).float()[:, :3] + 1) / 2

@@ -74,8 +74,8 @@ def _set_taps(desc, taps: Sequence[Tuple[int, int]]):
         desc.tap_dx[i] = dx
 
 
-def fwd_taps(kh: int, kw: int, pad: int) -> List[Tuple[int, int]]:
-    return [(ky - pad, kx - pad) for ky in range(kh) for kx in range(kw)]
+def fwd_taps(kh: int, kw: int, pad: int, dilation: int = 1) -> List[Tuple[int, int]]:
+    return [(ky * dilation - pad, kx * dilation - pad) for ky in range(kh) for kx in range(kw)]
 
 
 def gemm_weight(weight: torch.Tensor, cin_pad: int) -> torch.Tensor:
@@ -337,6 +337,44 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if x.shape[-1] < weight.shape[1]:
         raise ValueError(f"conv2d: input has {x.shape[-1]} channels < weight Cin {weight.shape[1]}")
     return _Conv2dFn.apply(pad_channels(x, 8), weight, bias, resid, stride, padding, act, slope)
+
+
+def conv2d_infer(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride: int = 1,
+                 padding: int = 0, dilation: int = 1, act: int = ACT_NONE, slope: float = 0.2,
+                 resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Inference-only NHWC convolution with dilation (the frozen in-painting net's dilated residual blocks,
+    generator.py:452-461): the tap list carries the dilated offsets, everything else is conv2d's forward."""
+    x = _nhwc(pad_channels(x.detach(), 8))
+    n, h, w, cx = x.shape
+    cout, cin, kh, kw = weight.shape
+    if cx < cin:
+        raise ValueError(f"conv2d_infer: input has {cx} channels < weight Cin {cin}")
+    ho = (h + 2 * padding - dilation * (kh - 1) - 1) // stride + 1
+    wo = (w + 2 * padding - dilation * (kw - 1) - 1) // stride + 1
+    wp = pack_weight(weight.detach(), None, x.dtype, _roundup(cout, 128), cx, 0)
+    bp = bias.detach().float().contiguous() if bias is not None else None
+    out = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
+    _launch_conv(x, wp, out, bp, fwd_taps(kh, kw, padding, dilation), Hj=ho, Wj=wo, isy=stride, isx=stride,
+                 cout=cout, cout_gemm=cout, act=act, slope=slope, resid=_nhwc(resid) if resid is not None else None)
+    return out
+
+
+def conv_transpose2d_infer(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+                           stride: int = 2, padding: int = 1) -> torch.Tensor:
+    """Inference-only nn.ConvTranspose2d on NHWC (weight [Cin, Cout, kh, kw], generator.py:533-539): it is the
+    data gradient of the strided convolution with the same weight, i.e. one stride-1 gather per output-parity class
+    with that class's tap subset (conv_dgrad) -- no zero-stuffed input, no wasted MACs."""
+    x = _nhwc(pad_channels(x.detach(), 8))
+    n, h, w, cx = x.shape
+    cin, cout, kh, kw = weight.shape
+    if cx < cin or cout % 8:
+        raise ValueError("conv_transpose2d_infer: input channels must cover Cin and Cout must be a multiple of 8")
+    ho, wo = (h - 1) * stride - 2 * padding + kh, (w - 1) * stride - 2 * padding + kw
+    wt = pack_weight(weight.detach(), None, x.dtype, _roundup(cout, 128), cx, 1)    # columns past Cin are zero
+    y = conv_dgrad(x, wt, kh, kw, stride, padding, (ho, wo), cout)
+    if bias is not None:
+        y = y + bias.detach().to(y.dtype)
+    return y
 
 
 # ----------------------------------------------------------------------------

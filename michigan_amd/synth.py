@@ -31,8 +31,21 @@ def synth_batch(n: int, size: int, seed: int = 1234) -> Dict[str, torch.Tensor]:
     orient = torch.cat([torch.sin(2 * theta), torch.cos(2 * theta)], dim=1) * hair
     image = torch.rand(n, 3, size, size, generator=g) * 2 - 1
     noise = (torch.randn(n, 3, size, size, generator=g) * 0.25 + 0.5).clamp(0, 1)
-    return {"input_tag": onehot, "input_ref": onehot.clone(), "orient": orient, "image_tag": image,
-            "image_ref": image.clone(), "noise": noise, "hair": hair}
+    out = {"input_tag": onehot, "input_ref": onehot.clone(), "orient": orient, "image_tag": image,
+           "image_ref": image.clone(), "noise": noise, "hair": hair}
+    # inputs of the orientation in-painting branch (`inpaint_orient`, pix2pix_model.py:407-429): a rectangular hole
+    # inside the hair region and the RGB-coded orientation map in [0, 1].  Drawn from a second generator so that
+    # the tensors above stay bit-identical to the committed golden fixtures.
+    g2 = torch.Generator().manual_seed(seed + 7919)
+    hole = torch.zeros(n, 1, size, size)
+    for i in range(n):
+        y0, x0 = (torch.rand(2, generator=g2) * size * 0.3 + size * 0.2).long().tolist()
+        hh, ww = (torch.rand(2, generator=g2) * size * 0.2 + size * 0.15).long().tolist()
+        hole[i, :, y0:y0 + hh, x0:x0 + ww] = 1.0
+    out["hole"] = hole * hair
+    out["orient_rgb"] = torch.cat([(torch.cos(2 * theta) + 1) / 2, (torch.sin(2 * theta) + 1) / 2,
+                                   torch.zeros_like(theta)], dim=1) * hair
+    return out
 
 
 def synth_state_dict(template: Dict[str, torch.Tensor], seed: int = 0, gain: float = 1.0) -> Dict[str, torch.Tensor]:

@@ -35,8 +35,44 @@ def stats(t):
     return np.array([t.mean().item(), t.abs().mean().item(), t.std().item(), t.abs().max().item()])
 
 
+IG_CFG = dict(size=64, n=2, seed_w=7, seed_x=11, gain=1.0)
+
+
+def make_inpaint():
+    """Reference InpaintGenerator (eval mode, as models/pix2pix_model.py:196-198 runs it) on a seeded 4-channel input
+    and on the full `inpainting_orient` glue (pix2pix_model.py:407-429) at crop 64 -> its 256x256 working size."""
+    R.setup()
+    import types
+    from models.pix2pix_model import Pix2PixModel
+    opt = R.make_opt()
+    ig = R.build_inpaint(opt).eval()
+    ig.load_state_dict(synth_state_dict(ig.state_dict(), seed=IG_CFG["seed_w"], gain=IG_CFG["gain"]))
+    g = torch.Generator().manual_seed(IG_CFG["seed_x"])
+    x = torch.rand(IG_CFG["n"], 4, IG_CFG["size"], IG_CFG["size"], generator=g)
+    with torch.no_grad():
+        out = ig(x)
+    res = {"out": out.numpy()}
+    # the caller: hole / orient_rgb / noise / mask at crop 32 (the net itself always works at 256^2)
+    crop = 32
+    hole = (torch.rand(1, 1, crop, crop, generator=g) > 0.6).float()
+    orient_rgb = torch.rand(1, 3, crop, crop, generator=g)
+    noise = torch.rand(1, 3, crop, crop, generator=g)
+    mask = (torch.rand(1, 1, crop, crop, generator=g) > 0.3).float()
+    shim = types.SimpleNamespace(opt=types.SimpleNamespace(crop_size=crop), netIG=ig)
+    with torch.no_grad():
+        o_rgb, o2 = Pix2PixModel.inpainting_orient(shim, hole, orient_rgb, noise, mask)
+    res.update({"glue.out_rgb": o_rgb.numpy(), "glue.orient": o2.numpy()})
+    np.savez_compressed(os.path.join(OUT, "inpaint_c64.npz"), **res)
+    with open(os.path.join(OUT, "inpaint_config.json"), "w") as fh:
+        json.dump(IG_CFG, fh)
+    with open(os.path.join(OUT, "inpaint_state_dict_contract.json"), "w") as fh:
+        json.dump({k: list(v.shape) for k, v in ig.state_dict().items()}, fh)
+    print("inpaint golden: out mean %.4f std %.4f" % (out.mean().item(), out.std().item()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    make_inpaint()
     torch.manual_seed(0)
     opt = R.make_opt(ngf=CFG["ngf"], ndf=CFG["ndf"], crop_size=CFG["crop_size"], random_expand_mask=True,
                      wide_edge=CFG["wide_edge"], lambda_feat=CFG["lambda_feat"], lambda_vgg=CFG["lambda_vgg"])

@@ -329,6 +329,63 @@ def discriminate(sd_d: SD, input_tag, orient_in, fake, real, training=True, upda
     return pf, pr
 
 
+# ---------------------------------------------------------------------------
+# frozen orientation in-painting network, eval mode
+# ---------------------------------------------------------------------------
+def _sn_weight_eval(sd: SD, prefix: str, dim: int = 0):
+    """torch.nn.utils.spectral_norm in eval mode: no power iteration, sigma = u^T W v with W flattened with `dim`
+    first (dim = 1 for ConvTranspose2d, torch/nn/utils/spectral_norm.py)."""
+    w = sd[prefix + "weight_orig"]
+    wm = w if dim == 0 else w.transpose(0, dim)
+    wm = wm.reshape(wm.shape[0], -1)
+    return w / torch.dot(sd[prefix + "weight_u"], torch.mv(wm, sd[prefix + "weight_v"]))
+
+
+def inpaint_generator(sd: SD, x, blocks: int = 12):
+    """InpaintGenerator.forward (skips=False), generator.py:489-575: reflect-padded 7x7 SN conv, two 4x4 stride-2 SN
+    convs (each InstanceNorm + LeakyReLU 0.2), 12 dilated residual blocks (generator.py:450-464), self-attention
+    over the H*W positions (generator.py:467-486), two 4x4 stride-2 SN transposed convs (InstanceNorm + ReLU), a
+    reflect-padded 7x7 conv, (tanh + 1) / 2."""
+    def rp(t, p):
+        return F.pad(t, (p, p, p, p), mode="reflect")
+    y = F.conv2d(rp(x, 3), _sn_weight_eval(sd, "encoder.1."), sd["encoder.1.bias"])
+    y = F.leaky_relu(instance_norm(y), 0.2)
+    y = F.leaky_relu(instance_norm(F.conv2d(y, _sn_weight_eval(sd, "encoder.4."), sd["encoder.4.bias"], stride=2, padding=1)), 0.2)
+    y = F.leaky_relu(instance_norm(F.conv2d(y, _sn_weight_eval(sd, "encoder.7."), sd["encoder.7.bias"], stride=2, padding=1)), 0.2)
+    for i in range(blocks):
+        pre = "middle.%d.conv_block." % i
+        t = F.conv2d(rp(y, 2), _sn_weight_eval(sd, pre + "1."), sd[pre + "1.bias"], dilation=2)
+        t = F.relu(instance_norm(t))
+        t = instance_norm(F.conv2d(rp(t, 1), _sn_weight_eval(sd, pre + "5."), sd[pre + "5.bias"]))
+        y = y + t
+    pre = "middle.%d." % blocks
+    n, c, h, w = y.shape
+    q = F.conv2d(y, sd[pre + "query_conv.weight"], sd[pre + "query_conv.bias"]).view(n, -1, h * w).permute(0, 2, 1)
+    k = F.conv2d(y, sd[pre + "key_conv.weight"], sd[pre + "key_conv.bias"]).view(n, -1, h * w)
+    attn = torch.softmax(torch.bmm(q, k), dim=-1)
+    v = F.conv2d(y, sd[pre + "value_conv.weight"], sd[pre + "value_conv.bias"]).view(n, -1, h * w)
+    y = torch.cat([y, torch.bmm(v, attn.permute(0, 2, 1)).view(n, c, h, w)], dim=1)
+    y = F.relu(instance_norm(F.conv_transpose2d(y, _sn_weight_eval(sd, "decoder.0.", 1), sd["decoder.0.bias"], stride=2, padding=1)))
+    y = F.relu(instance_norm(F.conv_transpose2d(y, _sn_weight_eval(sd, "decoder.3.", 1), sd["decoder.3.bias"], stride=2, padding=1)))
+    y = F.conv2d(rp(y, 3), sd["decoder.7.weight"], sd["decoder.7.bias"])
+    return (torch.tanh(y) + 1) / 2
+
+
+def inpainting_orient(sd_ig: SD, hole, orient_rgb, noise, mask, crop_size: int):
+    """Pix2PixModel.inpainting_orient (pix2pix_model.py:407-429): fill the hole of the RGB-coded orientation map with
+    the frozen net at 256x256 and convert the result to the generator's 2-channel orientation input."""
+    inp = torch.cat([orient_rgb * (1 - hole) + noise * hole, hole], dim=1)
+    if crop_size != 256:
+        inp = F.interpolate(inp, size=(256, 256), mode="nearest")
+    out = inpaint_generator(sd_ig, inp)
+    if crop_size != 256:
+        out = F.interpolate(out, size=(crop_size, crop_size), mode="nearest")
+    out = out * hole + orient_rgb * (1 - hole)
+    o2 = (out[:, :-1] - 0.5) * 2
+    orient = torch.stack([o2[:, 1], o2[:, 0]], dim=1) * mask
+    return out, orient
+
+
 def gabor_bank():
     """gabor_fn for the 32 orientations of L1OLoss, loss.py:215-243,288-293 (fp32 [32,1,17,17])."""
     r = torch.arange(-8, 9).float()

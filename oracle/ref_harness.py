@@ -114,6 +114,13 @@ def build_discriminator(opt):
     return MultiscaleDiscriminator(opt)
 
 
+def build_inpaint(opt):
+    """The reference's frozen orientation in-painting generator (generator.py:489-575), random init."""
+    setup()
+    from models.networks.generator import InpaintGenerator
+    return InpaintGenerator(opt)
+
+
 def build_vgg():
     setup()
     from models.networks.architecture import VGG19
