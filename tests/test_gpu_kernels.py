@@ -92,6 +92,9 @@ CONV_CASES = [
     (16, 32, 3, 1, 1, 12, 12, 2),       # packed taps: 2 (bf16) taps per K chunk, 8 taps per wgrad N tile
     (32, 64, 3, 1, 1, 10, 10, 1),       # Cin == one bf16 chunk; wgrad packs 4 taps per tile
     (8, 128, 7, 1, 3, 14, 14, 1),       # 49 taps, packed (ragged last chunk: 49 = 12*4 + 1)
+    (2048, 128, 3, 1, 1, 8, 8, 2),      # low-resolution long-K: split-K forward (gamma/beta dgrad shape)
+    (1024, 1024, 3, 1, 1, 8, 8, 2),     # 1024-channel block at the 8x8 latent: split-K forward and dgrad
+    (512, 200, 3, 1, 1, 7, 5, 1),       # split-K with ragged pixels / channels
 ]
 
 
