@@ -235,6 +235,17 @@ int mg_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
                  int64_t numel, float lr, float beta1, float beta2, float eps, int32_t step,
                  float grad_scale, void* stream);
 
+/* torch.nn.utils.spectral_norm (dim 0, one power iteration) as applied to every G / D convolution
+ * (architecture.py:39-42, normalization.py:28-29), around the two gemv calls the host issues:
+ *   mg_sn_normalize: dst (and dst2, optional) = t / max(||t||_2, eps); sigma (optional) = dst . t
+ *   mg_sn_scale:     out = w / sigma[0]                                   (numel a multiple of 4)
+ *   mg_sn_bwd:       out[r][c] = (g[r][c] - s[0] u[r] v[c]) / sigma[0]    (gradient through W / sigma, u and v constant,
+ *                    s = sum(g * W_sn)); all fp32, device scalars. */
+int mg_sn_normalize(const float* t, int32_t n, float eps, float* dst, float* dst2, float* sigma, void* stream);
+int mg_sn_scale(const float* w, const float* sigma, float* out, int64_t numel, void* stream);
+int mg_sn_bwd(const float* g, const float* u, const float* v, const float* s, const float* sigma, float* out,
+              int32_t rows, int32_t cols, void* stream);
+
 /* Hardware probes used by the test-suite (MFMA / ds_read_tr fragment maps). */
 int mg_probe_mfma_layout(float* out /* [3][64][16] */, void* stream);
 int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* out /* [64][4] */, void* stream);

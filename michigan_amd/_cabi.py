@@ -72,6 +72,9 @@ _PROTOS = {
     "mg_l1_mean_bwd": ([_vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
     "mg_gabor_argmax_fwd": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_gabor_argmax_bwd": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "mg_sn_normalize": ([_vp, _i32, _f32, _vp, _vp, _vp, _vp], _i32),
+    "mg_sn_scale": ([_vp, _vp, _vp, _i64, _vp], _i32),
+    "mg_sn_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp], _i32),
     "mg_adam_step": ([_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp], _i32),
     "mg_probe_mfma_layout": ([_vp, _vp], _i32),
     "mg_probe_tr16": ([_vp, _vp, _vp], _i32),

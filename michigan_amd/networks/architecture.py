@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
-from torch.nn.utils import spectral_norm
+from .spectral import spectral_norm
 
 from .. import ops
 from .layers import FusedReLU, HipConv2d

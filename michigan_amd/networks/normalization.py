@@ -6,7 +6,7 @@ import re
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from torch.nn.utils import spectral_norm
+from .spectral import spectral_norm
 
 from .. import ops
 from .layers import HipConv2d, HipInstanceNorm2d

@@ -391,6 +391,28 @@ class EmulatorBackend:
             out[..., c] = (dgray * wgt * 127.5).to(td)
         return 0
 
+    def mg_sn_normalize(self, t, n, eps, dst, dst2, sigma, stream=None):
+        tv = _view(t, (n,), torch.float32).double()
+        q = tv / max(tv.norm().item(), eps)
+        _view(dst, (n,), torch.float32)[:] = q.float()
+        if _addr(dst2):
+            _view(dst2, (n,), torch.float32)[:] = q.float()
+        if _addr(sigma):
+            _view(sigma, (1,), torch.float32)[0] = float((q.float().double() * tv).sum())
+        return 0
+
+    def mg_sn_scale(self, w, sigma, out, numel, stream=None):
+        s = _view(sigma, (1,), torch.float32)[0]
+        _view(out, (numel,), torch.float32)[:] = _view(w, (numel,), torch.float32) / s
+        return 0
+
+    def mg_sn_bwd(self, g, u, v, s, sigma, out, rows, cols, stream=None):
+        gv = _view(g, (rows, cols), torch.float32).double()
+        uv = torch.outer(_view(u, (rows,), torch.float32).double(), _view(v, (cols,), torch.float32).double())
+        sv, sg = _view(s, (1,), torch.float32)[0].double(), _view(sigma, (1,), torch.float32)[0].double()
+        _view(out, (rows, cols), torch.float32)[:] = ((gv - sv * uv) / sg).float()
+        return 0
+
     def mg_set_option(self, key, value):
         return 0
 

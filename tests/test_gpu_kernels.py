@@ -386,6 +386,32 @@ def test_reflect_pad_fwd_bwd(N, H, W, C, P, dt):
     _close("reflect pad vs torch", hip[0], want, 0.0 if dt == "f32" else TOL[dt])
 
 
+@pytest.mark.parametrize("train", [True, False], ids=["train", "eval"])
+@pytest.mark.parametrize("shape", [(64, 7, 4, 4), (128, 4, 3, 3), (256, 128, 3, 3)], ids=str)
+def test_fused_spectral_norm_matches_torch(shape, train):
+    """FusedSpectralNorm (gemv + mg_sn_* kernels) vs torch.nn.utils.spectral_norm on the same module state:
+    normalised weight, in-place updated u / v buffers and the gradient w.r.t. weight_orig."""
+    import copy
+    import torch.nn as nn
+    from torch.nn.utils import spectral_norm as torch_sn
+    from michigan_amd.networks.spectral import spectral_norm as fused_sn
+    torch.manual_seed(shape[0] + shape[1])
+    base = nn.Conv2d(shape[1], shape[0], shape[2])
+    ref, mine = torch_sn(copy.deepcopy(base)).cuda(), fused_sn(copy.deepcopy(base)).cuda()
+    mine.load_state_dict(ref.state_dict())
+    ref.train(train); mine.train(train)
+    gy = torch.randn(shape, device="cuda")
+    outs = []
+    for m in (ref, mine):
+        for hook in m._forward_pre_hooks.values():
+            hook(m, None)                                   # the pre-forward hook computes m.weight
+        w = m.weight
+        (gw,) = torch.autograd.grad(w, m.weight_orig, gy)
+        outs.append((w.detach(), m.weight_u.clone(), m.weight_v.clone(), gw))
+    for name, a, b in zip(("weight", "u", "v", "grad"), outs[1], outs[0]):
+        _close(f"spectral {shape} {name}", a, b, 2e-5)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_l1_mean_fused(dt):
     from michigan_amd import ops
