@@ -87,7 +87,7 @@ def main():
     backend = os.environ.get("MG_BENCH_BACKEND", "nccl")       # "gloo" lets two ranks share one GPU in a smoke test
     local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or os.environ.get("MG_DP_FORCE") == "1":     # MG_DP_FORCE: one-rank RCCL exercise of the DP path (michigan_amd/parallel.py)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:

@@ -27,6 +27,7 @@ class FlatAdam:
         self.step_count = 0
         self.group = group
         self.world = dist.get_world_size(group) if (group is not None) else 1
+        self.dp = group is not None                  # world == 1 only under the MG_DP_FORCE test hook
         self._build_arena()
         # bucket = contiguous [lo, hi) slice of the arena; params were laid out in REVERSE registration
         # order so that backward fills the arena front to back.
@@ -44,7 +45,7 @@ class FlatAdam:
         self._pending = [b[2] for b in self.buckets]
         self._work, self._stream, self._hooks = [], None, []
         self.overlap = True
-        if self.world > 1:
+        if self.dp:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -106,7 +107,7 @@ class FlatAdam:
         """After backward(): reduce whatever has not been launched yet (buckets holding parameters that
         received no gradient, or everything when overlap is off) and wait.  The 1/world average is
         folded into the Adam kernel's grad_scale."""
-        if self.world == 1:
+        if not self.dp:
             return
         for i, left in enumerate(self._pending):
             if left > 0 or not self.overlap:

@@ -13,6 +13,7 @@ has been produced (autograd post-accumulate hooks), overlapping with the remaini
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -26,7 +27,11 @@ _GROUP = None
 def init(group=None):
     """Enable cross-rank batch-norm statistics and gradient reduction on `group` (default: WORLD)."""
     global _GROUP
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    # MG_DP_FORCE=1 (test hook): keep every collective in the step even with a single rank, so that the RCCL call
+    # pattern (side-stream bucket all-reduces from autograd hooks, sync-BN reductions inside forward / backward) can
+    # be exercised on a one-GPU box.
+    forced = os.environ.get("MG_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized()
+    if not forced and (not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1):
         _GROUP = None
         ops.SYNC_BN_GROUP = None
         return None
