@@ -60,9 +60,10 @@ class SPADE(nn.Module):
     def forward(self, x, segmap, act=ops.ACT_NONE, stats=None, return_stats=False):
         n, h, w, c = x.shape
         seg = segmap.at(h, w) if isinstance(segmap, SegPyramid) else SegPyramid(segmap, x.dtype).at(h, w)
-        st = self.param_free_norm.statistics(x, stats)
+        pending = self.param_free_norm.statistics_begin(x, stats)      # sums + async all-reduce (data parallel)
+        actv = self.mlp_shared[0](seg, act=ops.ACT_RELU)               # independent of the statistics: overlaps with it
+        st = self.param_free_norm.statistics_finish(pending)
         mean, rstd, count = st[0], st[1], st[2]
-        actv = self.mlp_shared[0](seg, act=ops.ACT_RELU)
         out = ops.spade_modulate(x, actv, self.mlp_gamma.weight, self.mlp_gamma.bias,
                                  self.mlp_beta.weight, self.mlp_beta.bias, mean, rstd, count,
                                  act=act, slope=0.2)

@@ -53,6 +53,19 @@ class SynchronizedBatchNorm2d(nn.Module):
             ops.advance_running_stats(sums, count, self.eps, self.momentum, self.running_mean, self.running_var)
         return mean, rstd, count, sums
 
+    def statistics_begin(self, x, shared=None):
+        """statistics() in two halves so that the caller can put independent work between the (asynchronous)
+        cross-rank reduction and its use: returns a pending object for statistics_finish."""
+        if self.training and shared is None:
+            return ("pending", ops.batch_stats_begin(x))
+        return ("ready", self.statistics(x, shared))
+
+    def statistics_finish(self, pending):
+        kind, val = pending
+        if kind == "ready":
+            return val
+        return ops.batch_stats_finish(val, self.eps, self.momentum, self.running_mean, self.running_var)
+
     def forward(self, x):                                          # NHWC, stand-alone use
         mean, rstd, _, _ = self.statistics(x)
         y = (x.float() - mean) * rstd

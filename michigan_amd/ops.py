@@ -380,30 +380,48 @@ def conv_transpose2d_infer(x: torch.Tensor, weight: torch.Tensor, bias: Optional
 # ----------------------------------------------------------------------------
 # batch statistics (sync-BN) and SPADE modulation
 # ----------------------------------------------------------------------------
-def batch_stats(x: torch.Tensor, eps: float = 1e-5, momentum: float = 0.1,
-                running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None):
-    """Per-channel batch statistics of an NHWC tensor over (N, H, W) [x all ranks of SYNC_BN_GROUP].
-
-    Returns (mean, rstd, count); rstd = 1/sqrt(biased_var + eps) as F.batch_norm computes it on one device
-    (sync_batchnorm/batchnorm.py:65-68).  Three launches: two-stage channel sums, [one all-reduce of the 2C sums
-    when data parallel,] finalize (which also advances the running statistics when given).  Every rank holds the
-    same number of elements (equal per-GPU batch), so the global count is local count x world size -- no host
-    sync.  No autograd here: the dependence of the statistics on x is handled by the consumers' backward kernels.
-    """
+def batch_stats_begin(x: torch.Tensor):
+    """First half of batch_stats: local channel sums and, when data parallel, the all-reduce of the 2C sums launched
+    ASYNCHRONOUSLY -- the caller runs work that does not need the statistics (SPADE's mlp_shared conv) before
+    batch_stats_finish, so the latency-bound collective overlaps with it.  Returns an opaque pending tuple."""
     with torch.no_grad():
         x = _nhwc(x)
         c = x.shape[-1]
         count = x.numel() // c
         sums = channel_sums(x)
+        work = None
         if SYNC_BN_GROUP is not None:
             import torch.distributed as dist
-            dist.all_reduce(sums, group=SYNC_BN_GROUP)
+            work = dist.all_reduce(sums, group=SYNC_BN_GROUP, async_op=True)
             count *= dist.get_world_size(SYNC_BN_GROUP)
-        mean = torch.empty(c, dtype=torch.float32, device=x.device)
-        rstd = torch.empty(c, dtype=torch.float32, device=x.device)
+        return sums, work, count, c
+
+
+def batch_stats_finish(pending, eps: float = 1e-5, momentum: float = 0.1,
+                       running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None):
+    """Second half: wait for the reduction (a stream dependency, not a host block, on RCCL) and finalize."""
+    sums, work, count, c = pending
+    with torch.no_grad():
+        if work is not None:
+            work.wait()
+        mean = torch.empty(c, dtype=torch.float32, device=sums.device)
+        rstd = torch.empty(c, dtype=torch.float32, device=sums.device)
         C.backend().mg_norm_finalize(_p(sums), 1, c, float(count), eps, momentum, _p(running_mean), _p(running_var),
-                                     _p(mean), _p(rstd), _stream(x))
+                                     _p(mean), _p(rstd), _stream(sums))
         return mean, rstd, count, sums
+
+
+def batch_stats(x: torch.Tensor, eps: float = 1e-5, momentum: float = 0.1,
+                running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None):
+    """Per-channel batch statistics of an NHWC tensor over (N, H, W) [x all ranks of SYNC_BN_GROUP].
+
+    Returns (mean, rstd, count, sums); rstd = 1/sqrt(biased_var + eps) as F.batch_norm computes it on one device
+    (sync_batchnorm/batchnorm.py:65-68).  Three launches: two-stage channel sums, [one all-reduce of the 2C sums
+    when data parallel,] finalize (which also advances the running statistics when given).  Every rank holds the
+    same number of elements (equal per-GPU batch), so the global count is local count x world size -- no host
+    sync.  No autograd here: the dependence of the statistics on x is handled by the consumers' backward kernels.
+    """
+    return batch_stats_finish(batch_stats_begin(x), eps, momentum, running_mean, running_var)
 
 
 def advance_running_stats(sums: torch.Tensor, count, eps: float, momentum: float,
@@ -468,14 +486,10 @@ class _SpadeFn(torch.autograd.Function):
         be.mg_norm_bwd_reduce(_p(dh), _p(h), _p(x), _p(g1), _dt(x), 1, p, c, _p(mean), _p(rstd), act, slope,
                               _p(dgb), _p(sums), _p(ws), _stream(x))
         dx = dactv = dwg = dwb = dbg = dbb = None
-        if ctx.needs_input_grad[0]:
-            if SYNC_BN_GROUP is not None:
-                import torch.distributed as dist
-                dist.all_reduce(sums, group=SYNC_BN_GROUP)
-            s = (sums[0] / count).float().contiguous()
-            dx = torch.empty_like(x)
-            be.mg_norm_bwd_apply(_p(dh), _p(h), _p(x), _p(g1), _dt(x), 1, p, c, _p(mean), _p(rstd),
-                                 _p(s[0]), _p(s[1]), act, slope, _p(dx), _stream(x))
+        work = None
+        if ctx.needs_input_grad[0] and SYNC_BN_GROUP is not None:
+            import torch.distributed as dist
+            work = dist.all_reduce(sums, group=SYNC_BN_GROUP, async_op=True)    # overlaps with the gamma/beta conv's backward below
         if ctx.needs_input_grad[1]:
             wt = pack_weight(w_gamma, w_beta, x.dtype, _roundup(actv.shape[3], 128), rows, 1)
             dactv = conv_dgrad(dgb, wt, kh, kh, 1, pad, (hh, ww), actv.shape[3])
@@ -488,6 +502,13 @@ class _SpadeFn(torch.autograd.Function):
             db = res[1] if need_b else None
         elif need_b:
             db = channel_sums(dgb)[0, 0]
+        if ctx.needs_input_grad[0]:
+            if work is not None:
+                work.wait()
+            s = (sums[0] / count).float().contiguous()
+            dx = torch.empty_like(x)
+            be.mg_norm_bwd_apply(_p(dh), _p(h), _p(x), _p(g1), _dt(x), 1, p, c, _p(mean), _p(rstd),
+                                 _p(s[0]), _p(s[1]), act, slope, _p(dx), _stream(x))
         if db is not None:
             db = db.reshape(rows // 64, 2, 32)
             dbg, dbb = db[:, 0].reshape(-1)[:c], db[:, 1].reshape(-1)[:c]
