@@ -413,6 +413,77 @@ def test_fused_spectral_norm_matches_torch(shape, train):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("cin,cout,H,W,big", [(128, 128, 200, 176, 1), (128, 128, 200, 176, 0), (64, 64, 203, 181, 1),
+                                               (32, 200, 150, 210, 1), (256, 136, 97, 131, 0)], ids=str)
+def test_halo_conv_ragged_geometry(cin, cout, H, W, big, dt):
+    """The halo-tile kernels only engage on chip-filling launches, which the small contract cases above never are:
+    images whose height / width are not multiples of the 16x16 (or 8x16) tile and ragged channel counts, forward and
+    data gradient, against torch's own fp32 convolution."""
+    from michigan_amd import ops, _cabi
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(4, H, W, cin, generator=g).to(DT[dt]).cuda().requires_grad_()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    gy = torch.randn(4, H, W, cout, generator=g).to(DT[dt]).cuda()
+    be = _cabi.backend()
+    be.mg_set_option(4, big)
+    try:
+        y = ops.conv2d(x, w, b, padding=1, act=ops.ACT_LRELU)
+        (dx,) = torch.autograd.grad(y, x, gy)
+    finally:
+        be.mg_set_option(4, 1)
+    xr = x.detach().float().permute(0, 3, 1, 2).contiguous()
+    wr = w if dt == "f32" else w.bfloat16().float()
+    yr = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xr, wr, b, padding=1), 0.2)
+    # data gradient written out (the adjoint of a stride-1 conv is the transposed conv); act' through the output the
+    # kernel stored, which is what its backward is defined on
+    yq = y.detach().float().permute(0, 3, 1, 2)             # (pre-activations within rounding of 0 may differ in sign)
+    dpre = gy.float().permute(0, 3, 1, 2) * torch.where(yq > 0, 1.0, 0.2)
+    if dt == "bf16":
+        dpre = dpre.bfloat16().float()
+    dxr = torch.nn.functional.conv_transpose2d(dpre, wr, padding=1)
+    _close(f"halo ragged y {dt}", y, yr.permute(0, 2, 3, 1), 2e-5 if dt == "f32" else TOL[dt])
+    _close(f"halo ragged dx {dt}", dx, dxr.permute(0, 2, 3, 1), 5e-5 if dt == "f32" else TOL[dt])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("C,H,W", [(64, 200, 176), (136, 97, 131)], ids=str)
+def test_spade_halo_ragged_geometry(C, H, W, dt):
+    """SPADE epilogue on the halo-tile kernel (chip-filling, ragged tiles and channels): forward and the full backward
+    (batch statistics included) against torch autograd on the written-out formula, fp32 on the GPU."""
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(C)
+    x = (torch.randn(4, H, W, C, generator=g) * 1.5 + 0.3).to(DT[dt]).cuda().requires_grad_()
+    actv = torch.randn(4, H, W, 128, generator=g).clamp_min(0).to(DT[dt]).cuda().requires_grad_()
+    wg = (torch.randn(C, 128, 3, 3, generator=g) / 34).cuda().requires_grad_()
+    wb = (torch.randn(C, 128, 3, 3, generator=g) / 34).cuda().requires_grad_()
+    bg = (torch.randn(C, generator=g) * 0.1).cuda().requires_grad_()
+    bb = (torch.randn(C, generator=g) * 0.1).cuda().requires_grad_()
+    gh = torch.randn(4, H, W, C, generator=g).to(DT[dt]).cuda()
+    mean, rstd, cnt, _ = ops.batch_stats(x)
+    h = ops.spade_modulate(x, actv, wg, bg, wb, bb, mean, rstd, cnt, act=ops.ACT_NONE)
+    got = torch.autograd.grad(h, (x, actv, wg, wb, bg, bb), gh)
+
+    q = (lambda t: t.bfloat16().float()) if dt == "bf16" else (lambda t: t)
+    xr = x.detach().float().permute(0, 3, 1, 2).contiguous().requires_grad_()
+    ar = actv.detach().float().permute(0, 3, 1, 2).contiguous().requires_grad_()
+    wgr, wbr = q(wg.detach()).requires_grad_(), q(wb.detach()).requires_grad_()
+    bgr, bbr = bg.detach().clone().requires_grad_(), bb.detach().clone().requires_grad_()
+    mu = xr.mean(dim=(0, 2, 3), keepdim=True)
+    var = xr.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    gam = torch.nn.functional.conv2d(ar, wgr, bgr, padding=1)
+    bet = torch.nn.functional.conv2d(ar, wbr, bbr, padding=1)
+    hr = (xr - mu) / torch.sqrt(var + 1e-5) * (1 + gam) + bet
+    want = torch.autograd.grad(hr, (xr, ar, wgr, wbr, bgr, bbr), gh.float().permute(0, 3, 1, 2))
+    tol = 1e-4 if dt == "f32" else TOL[dt]
+    _close(f"spade halo h {dt}", h, hr.permute(0, 2, 3, 1), tol)
+    _close(f"spade halo dx {dt}", got[0], want[0].permute(0, 2, 3, 1), tol * 4)
+    _close(f"spade halo dactv {dt}", got[1], want[1].permute(0, 2, 3, 1), tol * 4)
+    for name, a, b in zip(("dwg", "dwb", "dbg", "dbb"), got[2:], want[2:]):
+        _close(f"spade halo {name} {dt}", a, b, 2e-3 if dt == "f32" else 6 * TOL[dt])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_l1_mean_fused(dt):
     from michigan_amd import ops
     g = torch.Generator().manual_seed(12)
