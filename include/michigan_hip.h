@@ -58,7 +58,9 @@ enum { MG_OK = 0, MG_ERR_ARG = 1, MG_ERR_LAUNCH = 2, MG_ERR_UNSUPPORTED = 3 };
  * Cin must be a multiple of 8 (host pads small channel counts with zeros).
  *
  * Epilogues
- *   MG_EPI_PLAIN: v = acc + bias[co] (+ resid[n,oy,ox,co]) ; out = act(v)   (bias has Cout_gemm entries)
+ *   MG_EPI_PLAIN: v = acc + bias[co] (+ resid[n,oy,ox,co]) ; out = act(v)   (bias has Cout_gemm entries);
+ *                 if x != NULL: out = (x[n,oy,ox,co] > 0) ? out : 0  -- a data gradient masked by the ReLU whose
+ *                 output x the forward conv consumed (saves the separate activation-backward pass)
  *   MG_EPI_SPADE: GEMM rows come in blocks of 64 = [32 gamma rows | 32 beta rows]
  *                 of the same 32 output channels (mlp_gamma/mlp_beta fused,
  *                 normalization.py:112-116).  For output channel c:
@@ -73,7 +75,7 @@ typedef struct mg_conv_desc {
     void*       out;       /* [N][Hout][Wout][Cout]                           */
     const float* bias;     /* [Cout_gemm] (GEMM row order) or NULL            */
     const void* resid;     /* PLAIN: same shape/dtype as out, or NULL         */
-    const void* x;         /* SPADE: un-normalised activations, shape of out  */
+    const void* x;         /* SPADE: un-normalised activations; PLAIN: optional ReLU-output mask; shape of out */
     const float* mean;     /* SPADE: [Cout]                                   */
     const float* rstd;     /* SPADE: [Cout]                                   */
     void*       gamma_out; /* SPADE: optional (1+gamma), shape/dtype of out   */

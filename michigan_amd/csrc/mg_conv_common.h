@@ -144,6 +144,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
 
     if constexpr (EPI == MG_EPI_PLAIN) {
         const T* __restrict__ Res = reinterpret_cast<const T*>(d.resid);
+        const T* __restrict__ Msk = reinterpret_cast<const T*>(d.x);          // optional ReLU-output mask (dgrad)
         static_for<0, MT>([&](auto mt_) {
             constexpr int mt = decltype(mt_)::value;
             const int lr = wm * MT * 32 + mt * 32 + hi * 4;       // + rq*8: this lane's GEMM rows inside the tile
@@ -152,12 +153,19 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
             for (int rq = 0; rq < 4; ++rq) bias4[rq] = *reinterpret_cast<const f32x4_t*>(par + lr + rq * 8);
             static_for<0, NT>([&](auto nt_) {
                 constexpr int nt = decltype(nt_)::value;
-                f32x4_t rv[4];
+                f32x4_t rv[4], mk[4];
                 if (Res) {
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
                         const int co = m0 + lr + rq * 8;
                         rv[rq] = ET<T>::load4(Res + opix[nt] + (co < d.Cout ? co : 0));
+                    }
+                }
+                if (Msk) {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int co = m0 + lr + rq * 8;
+                        mk[rq] = ET<T>::load4(Msk + opix[nt] + (co < d.Cout ? co : 0));
                     }
                 }
 #pragma unroll
@@ -168,7 +176,8 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
                     for (int j = 0; j < 4; ++j) {
                         float t = acc[mt][nt][rq * 4 + j] + bias4[rq][j];
                         if (Res) t += rv[rq][j];
-                        v[j] = mg_act_fast(t, neg, relu);
+                        t = mg_act_fast(t, neg, relu);
+                        v[j] = (Msk && !(mk[rq][j] > 0.f)) ? 0.f : t;
                     }
                     if (pok[nt] && co < d.Cout) ET<T>::store4(Out + opix[nt] + co, v);
                 }
@@ -251,12 +260,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT
                         for (int j = 0; j < 4; ++j) v[j] += (co + j < d.Cout_gemm) ? d.bias[co + j] : 0.f;
                     }
                     const size_t o = opix * d.Cout + co;
+                    const T* __restrict__ Msk = reinterpret_cast<const T*>(d.x);
                     if ((d.Cout & 3) == 0) {
                         if (Res) { f32x4_t rv = ET<T>::load4(Res + o);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] += rv[j]; }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = mg_act(v[j], d.act, d.slope);
+                        if (Msk) { const f32x4_t mk = ET<T>::load4(Msk + o);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) if (!(mk[j] > 0.f)) v[j] = 0.f; }
                         ET<T>::store4(Out + o, v);
                     } else {
 #pragma unroll
@@ -264,7 +277,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT
                             if (co + j < d.Cout) {
                                 float s = v[j];
                                 if (Res) s += ET<T>::load1(Res + o + j);
-                                ET<T>::store1(Out + o + j, mg_act(s, d.act, d.slope));
+                                s = mg_act(s, d.act, d.slope);
+                                if (Msk && !(ET<T>::load1(Msk + o + j) > 0.f)) s = 0.f;
+                                ET<T>::store1(Out + o + j, s);
                             }
                         }
                     }

@@ -99,12 +99,12 @@ def pad_channels(x: torch.Tensor, mult: int = 8) -> torch.Tensor:
 # ----------------------------------------------------------------------------
 def _launch_conv(inp, wt, out, bias, taps, *, Hj, Wj, isy, isx, osy=1, osx=1, ooy=0, oox=0,
                  cout, cout_gemm, act=ACT_NONE, slope=0.2, resid=None,
-                 spade_x=None, mean=None, rstd=None, gamma_out=None, algo_cin=None):
+                 spade_x=None, mean=None, rstd=None, gamma_out=None, algo_cin=None, relu_mask=None):
     d = C.ConvDesc()
     d.in_, d.wt, d.out = inp.data_ptr(), wt.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.resid = resid.data_ptr() if resid is not None else None
-    d.x = spade_x.data_ptr() if spade_x is not None else None
+    d.x = spade_x.data_ptr() if spade_x is not None else (relu_mask.data_ptr() if relu_mask is not None else None)
     d.mean = mean.data_ptr() if mean is not None else None
     d.rstd = rstd.data_ptr() if rstd is not None else None
     d.gamma_out = gamma_out.data_ptr() if gamma_out is not None else None
@@ -164,6 +164,8 @@ def unpack_wgrad(dw: torch.Tensor, shape, two: bool = False):
     return (d0, d1) if two else d0
 
 
+FUSE_RELU_MASK = True   # fold a consumed ReLU's backward mask into the data-gradient epilogue (A/B switch)
+_RELU_MASKED = {}       # address of a ReLU-masked data gradient -> (address of the ReLU output it was masked with, version)
 _DGRAD_CLASSES = {}     # (kh, kw, stride, pad) -> [(py, px, taps, (lo, hi))], tap order of the class-sorted weight image
 _DGRAD_PERM = {}        # (kh, kw, stride, pad, device) -> index tensor that sorts the packed taps by parity class
 
@@ -189,7 +191,7 @@ def _dgrad_classes(kh: int, kw: int, stride: int, pad: int):
 
 
 def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, kh: int, kw: int, stride: int, pad: int,
-               in_hw: Tuple[int, int], cin: int) -> torch.Tensor:
+               in_hw: Tuple[int, int], cin: int, relu_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Data gradient of a forward conv.  dy is [N, Ho, Wo, Cg8]; wt is the dgrad image
     [taps, roundup(cin,128), Cg8] (pack_weight mode 1).  For stride s the output pixels split into s*s
     parity classes; each class is a stride-1 gather over dy with the subset of taps whose offset is
@@ -214,7 +216,15 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, kh: int, kw: int, stride: int
         if hj == 0 or wj == 0 or not taps:
             continue
         _launch_conv(dy, wt[lo:hi], dx, None, taps, Hj=hj, Wj=wj, isy=1, isx=1,
-                     osy=stride, osx=stride, ooy=py, oox=px, cout=cin, cout_gemm=cin)
+                     osy=stride, osx=stride, ooy=py, oox=px, cout=cin, cout_gemm=cin, relu_mask=relu_mask)
+    if relu_mask is not None:
+        # dx is already multiplied by the ReLU mask of the tensor the forward conv consumed; the producer of that
+        # tensor finds the record below and skips its activation-backward pass.  The record is keyed by dx's address
+        # and carries its version counter: a gradient that autograd summed out of place lives elsewhere, one it
+        # accumulated in place has a bumped version -- in both cases the producer masks again (harmless: idempotent
+        # for ReLU), so a skip can only happen for the very buffer this launch wrote.
+        assert relu_mask.shape == dx.shape and relu_mask.dtype == dx.dtype
+        _RELU_MASKED[dx.data_ptr()] = (relu_mask.data_ptr(), dx._version)
     return dx
 
 
@@ -280,7 +290,7 @@ def act_backward(dy: torch.Tensor, y: torch.Tensor, act: int, slope: float) -> t
 # ----------------------------------------------------------------------------
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, resid, stride, pad, act, slope):
+    def forward(ctx, x, weight, bias, resid, stride, pad, act, slope, x_relu=False):
         x = _nhwc(x)
         n, h, w, cx = x.shape
         cout, cin, kh, kw = weight.shape
@@ -299,6 +309,7 @@ class _Conv2dFn(torch.autograd.Function):
                      cout=cout, cout_gemm=cout, act=act, slope=slope, resid=resid, algo_cin=cin)
         ctx.save_for_backward(x, weight, out if act != ACT_NONE else None)
         ctx.cfg = (stride, pad, act, slope, bias is not None, resid is not None)
+        ctx.x_relu = bool(x_relu)
         return out
 
     @staticmethod
@@ -308,12 +319,16 @@ class _Conv2dFn(torch.autograd.Function):
         cout, cin, kh, kw = weight.shape
         cx = x.shape[3]
         dout = dout.contiguous()
-        dpre = act_backward(dout, out, act, slope)
+        if act == ACT_RELU and _RELU_MASKED.pop(dout.data_ptr(), None) == (out.data_ptr(), dout._version):
+            dpre = dout                                  # the consumer's dgrad epilogue already applied this ReLU's mask
+        else:
+            dpre = act_backward(dout, out, act, slope)
         dpre8 = pad_channels(dpre, 8)
         dx = dw = dbias = None
         if ctx.needs_input_grad[0]:
             wt = pack_weight(weight, None, x.dtype, _roundup(cx, 128), dpre8.shape[3], 1)
-            dx = conv_dgrad(dpre8, wt, kh, kw, stride, pad, (x.shape[1], x.shape[2]), cx)
+            dx = conv_dgrad(dpre8, wt, kh, kw, stride, pad, (x.shape[1], x.shape[2]), cx,
+                            relu_mask=x if (ctx.x_relu and FUSE_RELU_MASK) else None)
         need_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             res = conv_wgrad(x, dpre8, kh, kw, stride, pad, want_bias=need_b)
@@ -323,7 +338,7 @@ class _Conv2dFn(torch.autograd.Function):
         elif need_b:
             dbias = channel_sums(dpre8)[0, 0, :cout]
         dres = dpre if (has_resid and ctx.needs_input_grad[3]) else None
-        return dx, dw, dbias, dres, None, None, None, None
+        return dx, dw, dbias, dres, None, None, None, None, None
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride: int = 1,
@@ -336,7 +351,12 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     """
     if x.shape[-1] < weight.shape[1]:
         raise ValueError(f"conv2d: input has {x.shape[-1]} channels < weight Cin {weight.shape[1]}")
-    return _Conv2dFn.apply(pad_channels(x, 8), weight, bias, resid, stride, padding, act, slope)
+    xp = pad_channels(x, 8)
+    y = _Conv2dFn.apply(xp, weight, bias, resid, stride, padding, act, slope,
+                        xp is x and getattr(x, "_mg_relu_out", False))
+    if act == ACT_RELU:
+        y._mg_relu_out = True        # consumers may fold this ReLU's backward mask into their data-gradient epilogue
+    return y
 
 
 def conv2d_infer(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride: int = 1,
@@ -445,7 +465,8 @@ def _interleave32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 class _SpadeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, act, slope):
+    def forward(ctx, x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, act, slope, actv_relu=False):
+        ctx.actv_relu = bool(actv_relu)
         x, actv = _nhwc(x), _nhwc(actv)
         n, h, w, c = x.shape
         if actv.shape[:3] != x.shape[:3] or actv.dtype != x.dtype:
@@ -492,7 +513,8 @@ class _SpadeFn(torch.autograd.Function):
             work = dist.all_reduce(sums, group=SYNC_BN_GROUP, async_op=True)    # overlaps with the gamma/beta conv's backward below
         if ctx.needs_input_grad[1]:
             wt = pack_weight(w_gamma, w_beta, x.dtype, _roundup(actv.shape[3], 128), rows, 1)
-            dactv = conv_dgrad(dgb, wt, kh, kh, 1, pad, (hh, ww), actv.shape[3])
+            dactv = conv_dgrad(dgb, wt, kh, kh, 1, pad, (hh, ww), actv.shape[3],
+                               relu_mask=actv if (ctx.actv_relu and FUSE_RELU_MASK) else None)      # mlp_shared's ReLU (normalization.py:94-99)
         need_w = ctx.needs_input_grad[2] or ctx.needs_input_grad[4]
         need_b = ctx.needs_input_grad[3] or ctx.needs_input_grad[5]
         db = None
@@ -512,7 +534,7 @@ class _SpadeFn(torch.autograd.Function):
         if db is not None:
             db = db.reshape(rows // 64, 2, 32)
             dbg, dbb = db[:, 0].reshape(-1)[:c], db[:, 1].reshape(-1)[:c]
-        return dx, dactv, dwg, dbg, dwb, dbb, None, None, None, None, None
+        return dx, dactv, dwg, dbg, dwb, dbb, None, None, None, None, None, None
 
 
 def spade_modulate(x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, *, act=ACT_NONE, slope=0.2):
@@ -522,7 +544,8 @@ def spade_modulate(x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count,
     both to memory and makes ~12 elementwise passes).  The backward implements the full
     batch-norm gradient (statistics included), so `mean`/`rstd` enter as constants.
     """
-    return _SpadeFn.apply(x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, act, slope)
+    return _SpadeFn.apply(x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, act, slope,
+                          getattr(actv, "_mg_relu_out", False))
 
 
 # ----------------------------------------------------------------------------

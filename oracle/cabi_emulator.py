@@ -109,7 +109,10 @@ class EmulatorBackend:
             v = acc[..., :d.Cout]
             if _addr(d.resid):
                 v = v + _view(d.resid, (d.N, d.Hout, d.Wout, d.Cout), td).double()[:, oy, ox]
-            out[:, oy, ox] = _act(v, d.act, d.slope).to(td)
+            v = _act(v, d.act, d.slope)
+            if _addr(d.x):                                   # ReLU-output mask of a data gradient
+                v = v * (_view(d.x, (d.N, d.Hout, d.Wout, d.Cout), td).double()[:, oy, ox] > 0)
+            out[:, oy, ox] = v.to(td)
         else:
             c = d.Cout
             ch = torch.arange(c)
