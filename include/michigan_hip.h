@@ -159,7 +159,8 @@ int mg_norm_act_fwd(const void* x, void* y, int32_t dtype, int32_t G, int64_t P,
  * mg_norm_bwd_apply:  dx = rstd * (dxhat - s1[g][c] - xhat * s2[g][c])
  *     with s1 = sum_dxhat / n, s2 = sum_dxhat_xhat / n supplied by the host
  *     (after the cross-rank all-reduce for sync-BN).
- * Replaces autograd of normalization.py:105-116 + F.batch_norm / InstanceNorm.
+ * Replaces autograd of normalization.py:105-116 + F.batch_norm / InstanceNorm.  h (the activation's output) is
+ * read only for its sign and may be NULL when act == MG_ACT_NONE.
  * ------------------------------------------------------------------------- */
 int mg_norm_bwd_reduce(const void* dh, const void* h, const void* x, const void* g1,
                        int32_t dtype, int32_t G, int64_t P, int32_t C,

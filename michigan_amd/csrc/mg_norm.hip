@@ -71,7 +71,8 @@ __global__ __launch_bounds__(NTHR) void reduce_stage1(
                     for (int j = 0; j < 4; ++j) { s[j] += xv[j]; ss[j] += xv[j] * xv[j]; }
                 } else {
                     const f32x4_t dv = ET<T>::load4(dh + o);
-                    const f32x4_t hv = ET<T>::load4(h + o);
+                    f32x4_t hv = {1.f, 1.f, 1.f, 1.f};              // h only matters through the sign of the activation's output
+                    if (h) hv = ET<T>::load4(h + o);
                     f32x4_t gv = {1.f, 1.f, 1.f, 1.f};
                     if (g1) gv = ET<T>::load4(g1 + o);
                     f32x4_t dgam, dbet;
@@ -165,7 +166,8 @@ __global__ void norm_bwd_apply_kernel(const T* __restrict__ dh, const T* __restr
         const int g = (int)(pix / P);
         const size_t sc = (size_t)g * C + qd * 4;
         const f32x4_t dv = ET<T>::load4(dh + i * 4);
-        const f32x4_t hv = ET<T>::load4(h + i * 4);
+        f32x4_t hv = {1.f, 1.f, 1.f, 1.f};
+        if (h) hv = ET<T>::load4(h + i * 4);
         const f32x4_t xv = ET<T>::load4(x + i * 4);
         f32x4_t gv = {1.f, 1.f, 1.f, 1.f};
         if (g1) gv = ET<T>::load4(g1 + i * 4);
@@ -254,7 +256,8 @@ __global__ __launch_bounds__(NTHR) void norm_bwd_apply_vec(const T* __restrict__
             const int64_t p = p0 + k * step;
             if (p < P) {
                 const size_t o = base + (size_t)p * C;
-                VT<T>::load(dh + o, dv[k]); VT<T>::load(h + o, hv[k]); VT<T>::load(x + o, xv[k]);
+                VT<T>::load(dh + o, dv[k]); VT<T>::load(x + o, xv[k]);
+                if (h) VT<T>::load(h + o, hv[k]);
                 if (g1) VT<T>::load(g1 + o, gv[k]);
             }
         }
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(NTHR) void norm_bwd_apply_vec(const T* __restrict__
                 float o4[VEC];
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    float dxh = dv[k][j] * act_factor(hv[k][j], neg);
+                    float dxh = h ? dv[k][j] * act_factor(hv[k][j], neg) : dv[k][j];
                     if (g1) dxh *= gv[k][j];
                     o4[j] = r[j] * dxh - c1[j] - c2[j] * (xv[k][j] - m[j]);
                 }
@@ -471,7 +474,7 @@ extern "C" int mg_norm_bwd_reduce(const void* dh, const void* h, const void* x, 
                                   void* dgb, float* sums, void* partial, void* stream)
 {
     MG_CHECK_NORM_GEOM("mg_norm_bwd_reduce");
-    MG_CHECK_ARG(dh && h && x && mean && rstd && sums && partial, "mg_norm_bwd_reduce: null pointer");
+    MG_CHECK_ARG(dh && (h || act == MG_ACT_NONE) && x && mean && rstd && sums && partial, "mg_norm_bwd_reduce: null pointer");
     MG_CHECK_ARG(dgb == nullptr || G == 1, "mg_norm_bwd_reduce: dgb output requires G == 1");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MG_BF16)
@@ -485,7 +488,7 @@ extern "C" int mg_norm_bwd_apply(const void* dh, const void* h, const void* x, c
                                  int32_t act, float slope, void* dx, void* stream)
 {
     MG_CHECK_NORM_GEOM("mg_norm_bwd_apply");
-    MG_CHECK_ARG(dh && h && x && mean && rstd && s1 && s2 && dx, "mg_norm_bwd_apply: null pointer");
+    MG_CHECK_ARG(dh && (h || act == MG_ACT_NONE) && x && mean && rstd && s1 && s2 && dx, "mg_norm_bwd_apply: null pointer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t nq = (int64_t)G * P * (C / 4);
     if (act != MG_ACT_TANH && (dtype == MG_BF16 ? vec_geom_ok<uint16_t>(C) : vec_geom_ok<float>(C))) {

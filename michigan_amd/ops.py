@@ -504,7 +504,8 @@ class _SpadeFn(torch.autograd.Function):
         dgb = alloc((n, hh, ww, rows), dtype=x.dtype, device=x.device)
         sums = torch.empty((1, 2, c), dtype=torch.float32, device=x.device)
         ws = torch.empty(max(int(be.mg_stats_workspace(1, p, c)), 4), dtype=torch.uint8, device=x.device)
-        be.mg_norm_bwd_reduce(_p(dh), _p(h), _p(x), _p(g1), _dt(x), 1, p, c, _p(mean), _p(rstd), act, slope,
+        hp = _p(h) if act != ACT_NONE else None          # the activation's output is only read for its sign
+        be.mg_norm_bwd_reduce(_p(dh), hp, _p(x), _p(g1), _dt(x), 1, p, c, _p(mean), _p(rstd), act, slope,
                               _p(dgb), _p(sums), _p(ws), _stream(x))
         dx = dactv = dwg = dwb = dbg = dbb = None
         work = None
@@ -529,7 +530,7 @@ class _SpadeFn(torch.autograd.Function):
                 work.wait()
             s = (sums[0] / count).float().contiguous()
             dx = torch.empty_like(x)
-            be.mg_norm_bwd_apply(_p(dh), _p(h), _p(x), _p(g1), _dt(x), 1, p, c, _p(mean), _p(rstd),
+            be.mg_norm_bwd_apply(_p(dh), hp, _p(x), _p(g1), _dt(x), 1, p, c, _p(mean), _p(rstd),
                                  _p(s[0]), _p(s[1]), act, slope, _p(dx), _stream(x))
         if db is not None:
             db = db.reshape(rows // 64, 2, 32)

@@ -174,7 +174,7 @@ class EmulatorBackend:
     def _bwd_common(self, dh, h, x, g1, dtype, G, P, C, mean, rstd, act, slope):
         td = _TD[dtype]
         dhv = _view(dh, (G, P, C), td).double()
-        hv = _view(h, (G, P, C), td).double()
+        hv = _view(h, (G, P, C), td).double() if _addr(h) else torch.ones_like(dhv)    # optional when act == none
         xv = _view(x, (G, P, C), td).double()
         mu = _view(mean, (G, 1, C), torch.float32).double()
         rs = _view(rstd, (G, 1, C), torch.float32).double()
