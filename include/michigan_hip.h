@@ -253,9 +253,11 @@ int mg_sn_bwd(const float* g, const float* u, const float* v, const float* s, co
 int mg_probe_mfma_layout(float* out /* [3][64][16] */, void* stream);
 int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* out /* [64][4] */, void* stream);
 
-/* Tuning switch for A/B measurements: key 0 = conv pipeline (0 register-staged double buffer,
- * 1 LDS-DMA three-stage ring, default); key 1 = allow 256x256 tiles; key 2 = 3x3 halo-tile kernel.
- * Results are identical whatever the setting. */
+/* Tuning switches for A/B measurements (value 0 / 1, all default 1): key 0 = conv pipeline (0 register-staged
+ * double buffer, 1 LDS-DMA ring); 1 = allow 256x256 tiles; 2 = 3x3 halo-tile kernel; 3 = kernel-row 3x3 weight-
+ * gradient kernel; 4 = 128-channel x 16x16-pixel halo tiles; 5 = split-K for low-resolution long-K convolutions.
+ * Results agree within accumulation-order rounding whatever the setting (each setting is bit-reproducible except
+ * the weight gradients, which use fp32 atomics). */
 int         mg_set_option(int32_t key, int32_t value);
 
 /* sizeof(mg_conv_desc) (which=0) / sizeof(mg_wgrad_desc) (which=1): lets a

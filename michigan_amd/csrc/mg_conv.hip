@@ -15,6 +15,7 @@
 // pipe).  bf16 uses v_mfma_f32_32x32x16_bf16, f32 uses v_mfma_f32_32x32x2_f32
 // (exact fp32 fma chain) -- same tiling, same LDS image (64 B of K per row).
 
+int g_mg_conv_splitk = 1;        // deterministic split-K for low-resolution long-K layers (mg_set_option(5, v))
 int g_mg_conv_halo_big = 1;      // 128 channels x 16x16 pixel halo tiles where the launch is big enough (mg_set_option(4, v))
 int g_mg_conv_halo = 1;          // 3x3 stride-1 convs on the LDS halo-tile kernel (mg_set_option(2, v))
 int g_mg_conv_bigtiles = 1;      // allow the 128x256 / 256x256 tiles (mg_set_option(1, v))
@@ -22,6 +23,8 @@ extern int g_mg_wgrad3x3;          // mg_wgrad.hip (mg_set_option(3, v))
 int g_mg_conv_pipeline = 1;      // 0 = register-staged double buffer, 1 = LDS-DMA 3-stage ring (mg_set_option(0, v))
 
 #include "mg_conv_common.h"
+#include <map>
+#include <mutex>
 
 namespace {
 
@@ -195,6 +198,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (MT * NT >= 8 ? 2 : 3
         const int q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
+    const int ksp = tile / d.ntiles;        // split-K slice of this workgroup (0 when ksplit == 1)
+    tile -= ksp * d.ntiles;
     const int tm = tile % d.tiles_m, tn = tile / d.tiles_m;
     const int m0 = tm * TM;
     const int q0 = tn * TN;
@@ -220,7 +225,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (MT * NT >= 8 ? 2 : 3
     }
 
     const int nchunk = PACK ? 1 : (d.Cin + CH - 1) / CH;
-    const int nk = PACK ? (d.ntaps + d.tpc - 1) / d.tpc : d.ntaps * nchunk;
+    const int nk_all = PACK ? (d.ntaps + d.tpc - 1) / d.tpc : d.ntaps * nchunk;
+    // split-K: this workgroup walks K steps [kbeg, kbeg + nk) of the nk_all (tap, chunk) steps
+    const int kper = (nk_all + d.ksplit - 1) / d.ksplit;
+    const int kbeg = ksp * kper;
+    const int nk = min(nk_all, kbeg + kper) - kbeg;
     const int ptap = PACK ? (piece * EPP) / d.Cin : 0;
     const int pch  = PACK ? (piece * EPP) % d.Cin : 0;
 
@@ -257,8 +266,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (MT * NT >= 8 ? 2 : 3
                        : g_mg_zeros + (lane & 3) * 16;
         }
     };
+    bool fresh = true;                       // a K slice may start in the middle of a tap: decode on the first issue
     auto issue = [&](int stage, int tap, int chunk) {
-        if (PACK || chunk == 0 || (!tail_ok && chunk == nchunk - 1)) set_tap(tap, chunk);
+        if (PACK || chunk == 0 || fresh || (!tail_ok && chunk == nchunk - 1)) set_tap(tap, chunk);
+        fresh = false;
         const unsigned sbase = lds0 + stage * STAGE;
 #pragma unroll
         for (int j = 0; j < A_IPS; ++j) {
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (MT * NT >= 8 ? 2 : 3
     float* const par = reinterpret_cast<float*>(smem + NS * STAGE);
     conv_stage_params_dma<TM, EPI, NW>(d, m0, lds0 + NS * STAGE, wave, lane);
     // prologue: the first NS-1 chunks in flight
-    int tap = 0, chunk = 0;                 // position of the NEXT chunk to issue
+    int tap = kbeg / nchunk, chunk = kbeg - tap * nchunk;     // position of the NEXT chunk to issue
     auto advance = [&]() { if (++chunk == nchunk) { chunk = 0; ++tap; } };
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -305,7 +316,85 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? (MT * NT >= 8 ? 2 : 3
         islot = (islot == NS - 1) ? 0 : islot + 1;
     }
 
+    if (d.ksplit > 1) {
+        wait_vmcnt<0>();                    // (a slice without K steps still has its parameter DMA in flight)
+        // partial sums of this K slice: plain fp32 stores into its own slab ws[ksp][q][co] (a slice that got no K
+        // steps stores zeros); conv_splitk_finish adds the slabs in a fixed order -> bit-reproducible
+        static_for<0, MT * NT>([&](auto i_) {
+            constexpr int mt = decltype(i_)::value / NT, nt = decltype(i_)::value % NT;
+            const int q = q0 + wn * NT * 32 + nt * 32 + l31;
+            if (q >= d.ngemm) return;
+            float* row = d.ws + ((size_t)ksp * d.ngemm + q) * d.Cout_gemm;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int co = m0 + wm * MT * 32 + mt * 32 + rq * 8 + hi * 4;
+                if (co < d.Cout_gemm) {
+                    f32x4_t v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][rq * 4 + j];
+                    *reinterpret_cast<f32x4_t*>(row + co) = v;
+                }
+            }
+        });
+        return;
+    }
     conv_epilogue<T, MT, NT, EPI, TM>(d, acc, m0, LinearPixMap{d, q0, HWj}, wm, wn, l31, hi, par);
+}
+
+// out[opix][co..co+3] = act(sum_s ws[s][q][co..] + bias + resid) for a split-K launch (PLAIN epilogue, Cout % 4 == 0)
+template <typename T>
+__global__ void conv_splitk_finish(const ConvK d)
+{
+    const int HWj = d.Hj * d.Wj, c4 = d.Cout / 4;
+    const long n = (long)d.ngemm * c4;
+    T* __restrict__ Out = reinterpret_cast<T*>(d.out);
+    const T* __restrict__ Res = reinterpret_cast<const T*>(d.resid);
+    const T* __restrict__ Msk = reinterpret_cast<const T*>(d.x);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % c4) * 4;
+        const int q = (int)(i / c4);
+        const int nimg = q / HWj, r = q - nimg * HWj;
+        const int jy = r / d.Wj, jx = r - jy * d.Wj;
+        const size_t o = (size_t)((nimg * d.Hout + jy * d.osy + d.ooy) * d.Wout + jx * d.osx + d.oox) * d.Cout + co;
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+        if (co < d.Cout_gemm) {
+            for (int s = 0; s < d.ksplit; ++s) {
+                const f32x4_t p = *reinterpret_cast<const f32x4_t*>(d.ws + ((size_t)s * d.ngemm + q) * d.Cout_gemm + co);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += p[j];
+            }
+            if (d.bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += d.bias[co + j];
+            }
+        }
+        if (Res) { const f32x4_t rv = ET<T>::load4(Res + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += rv[j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = mg_act(v[j], d.act, d.slope);
+        if (Msk) { const f32x4_t mk = ET<T>::load4(Msk + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (!(mk[j] > 0.f)) v[j] = 0.f; }
+        ET<T>::store4(Out + o, v);
+    }
+}
+
+// grow-only fp32 scratch for split-K partial sums, one buffer per stream (stream order makes reuse safe)
+float* splitk_workspace(hipStream_t st, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<hipStream_t, std::pair<float*, size_t>> pool;
+    std::lock_guard<std::mutex> lock(mu);
+    auto& e = pool[st];
+    if (e.second < bytes) {
+        if (e.first) { (void)hipStreamSynchronize(st); (void)hipFree(e.first); }
+        e.first = nullptr; e.second = 0;
+        const size_t want = bytes + bytes / 2;
+        if (hipMalloc(reinterpret_cast<void**>(&e.first), want) != hipSuccess) { e.first = nullptr; return nullptr; }
+        e.second = want;
+    }
+    return e.first;
 }
 
 template <typename T, int WM, int WN, int MT, int NT, int EPI, bool PACK>
@@ -338,6 +427,31 @@ int launch_conv_p(ConvK& k, hipStream_t st)
             const size_t stage = (size_t)(TM + TN) * ROWB;
             const size_t ldsr = (stage >= 32768 ? 4 : 3) * stage + 2 * TM * sizeof(float);
             auto kern = conv_taps_glds_kernel<T, WM, WN, MT, NT, EPI, PACK>;
+            k.ntiles = (int)nblk; k.ksplit = 1; k.ws = nullptr;
+            // Low-resolution layers with a long K loop (1024-channel blocks at the 8x8..32x32 latents, the gamma/beta
+            // dgrads there): a few dozen workgroups each pull hundreds of K steps through ONE CU's L2->LDS path
+            // (~50 GB/s per CU, 0.33 us per step whatever the tile, ring depth or wave count) while most CUs idle.
+            // Split K across workgroups: every slice stores its fp32 partial tile, a finishing pass adds the slices
+            // in a fixed order (deterministic) and applies bias / residual / activation.
+            if constexpr (EPI == MG_EPI_PLAIN && !PACK && WM == 2 && WN == 2 && MT == 2 && NT == 2) {
+                const int nchunk = (k.Cin * (int)sizeof(T) + ROWB - 1) / ROWB, nkk = k.ntaps * nchunk;
+                if (g_mg_conv_splitk && nblk <= 160 && nkk >= 64 && (k.Cout & 3) == 0 && (k.Cout_gemm & 3) == 0) {
+                    int S = (int)((384 + nblk - 1) / nblk);
+                    if (S > nkk / 16) S = nkk / 16;
+                    if (S > 16) S = 16;
+                    if (S >= 2) {
+                        k.ws = splitk_workspace(st, (size_t)S * k.ngemm * k.Cout_gemm * sizeof(float));
+                        if (k.ws == nullptr) return mg_fail(MG_ERR_LAUNCH, "mg_conv_taps: split-K scratch allocation failed");
+                        k.ksplit = S;
+                        hipLaunchKernelGGL(kern, dim3((unsigned)(nblk * S)), dim3(64 * WM * WN), ldsr, st, k);
+                        const long nel = (long)k.ngemm * (k.Cout / 4);
+                        const long fb = (nel + 255) / 256;
+                        hipLaunchKernelGGL(conv_splitk_finish<T>, dim3((unsigned)(fb > 2048 ? 2048 : fb)), dim3(256), 0, st, k);
+                        MG_CHECK_LAUNCH("mg_conv_taps(glds, split-K)");
+                        return MG_OK;
+                    }
+                }
+            }
             if (ldsr > 65536) {
                 static bool attr_done = false;       // raise the dynamic-LDS cap once per instantiation
                 if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr); attr_done = true; }
@@ -435,6 +549,7 @@ extern "C" int mg_conv_taps(const mg_conv_desc* d, void* stream)
     k.osy = d->osy; k.osx = d->osx; k.ooy = d->ooy; k.oox = d->oox;
     k.ntaps = d->ntaps; k.act = d->act; k.slope = d->slope;
     k.ngemm = d->N * d->Hj * d->Wj; k.tiles_m = 0; k.tpc = 1; k.tiles_y = k.tiles_x = 0;
+    k.ksplit = 1; k.ntiles = 1; k.ws = nullptr;
     for (int t = 0; t < MG_MAX_TAPS; ++t)
         k.tap[t] = t < d->ntaps ? (int)((((uint32_t)(int)d->tap_dy[t]) & 0xffffu) | (((uint32_t)(int)d->tap_dx[t]) << 16)) : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -448,5 +563,6 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 2 && (value == 0 || value == 1)) { g_mg_conv_halo = value; return MG_OK; }
     if (key == 3 && (value == 0 || value == 1)) { g_mg_wgrad3x3 = value; return MG_OK; }
     if (key == 4 && (value == 0 || value == 1)) { g_mg_conv_halo_big = value; return MG_OK; }
+    if (key == 5 && (value == 0 || value == 1)) { g_mg_conv_splitk = value; return MG_OK; }
     return mg_fail(MG_ERR_ARG, "mg_set_option: unknown key/value %d/%d", key, value);
 }

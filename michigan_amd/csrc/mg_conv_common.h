@@ -25,6 +25,8 @@ struct ConvK {              // kernel-side view of mg_conv_desc (passed by value
     int tpc;                // taps packed into one 64-byte K chunk (tiny Cin), 1 otherwise
     int tap[MG_MAX_TAPS];   // (dy & 0xffff) | (dx << 16)
     int tiles_y, tiles_x;   // halo kernel: spatial tiles per image
+    int ksplit, ntiles;     // generic LDS-DMA kernel: split-K factor (1 = off) and tiles per K slice
+    float* ws;              // split-K: fp32 partial sums [ksplit][ngemm][Cout_gemm]
 };
 namespace {
 

@@ -95,7 +95,11 @@ def test_discriminator_halves_decouple_at_512(hip_backend):
         both = D(x)
         D.load_state_dict(sdd)
         first = D(x[:2])
+    # per-sample (instance) norms: batch composition is irrelevant.  Not bitwise: the low-resolution layers choose their
+    # split-K factor from the launch size, so the fp32 summation order depends on the batch -- one bf16 ulp at most per
+    # layer, a coupling through shared statistics would show up as O(1) differences.
     for pa, pb in zip(both, first):
         for ta, tb in zip(pa, pb):
-            assert torch.equal(ta[:2].float(), tb.float())       # per-sample norms: batch composition is irrelevant
+            a, b = ta[:2].float(), tb.float()
+            assert (a - b).abs().max().item() <= 2.0 ** -6 * max(b.abs().max().item(), 1e-6)
     assert [tuple(t.shape[1:]) for t in both[0]] == [(64, 257, 257), (128, 129, 129), (256, 65, 65), (512, 66, 66), (1, 67, 67)]
