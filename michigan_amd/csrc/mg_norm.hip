@@ -35,7 +35,7 @@ static inline StatGeom stat_geom(int G, int64_t P, int C)
 }
 
 // MODE 0: plain (sum x, sum x^2).  MODE 1: norm backward (sum dxhat, sum dxhat*xhat [+ dgb]).
-template <typename T, int MODE>
+template <typename T, int MODE, bool HAS_H = true>
 __global__ __launch_bounds__(NTHR) void reduce_stage1(
     const T* __restrict__ x, const T* __restrict__ dh, const T* __restrict__ h, const T* __restrict__ g1,
     const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dgb,
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(NTHR) void reduce_stage1(
                 } else {
                     const f32x4_t dv = ET<T>::load4(dh + o);
                     f32x4_t hv = {1.f, 1.f, 1.f, 1.f};              // h only matters through the sign of the activation's output
-                    if (h) hv = ET<T>::load4(h + o);
+                    if constexpr (HAS_H) hv = ET<T>::load4(h + o);
                     f32x4_t gv = {1.f, 1.f, 1.f, 1.f};
                     if (g1) gv = ET<T>::load4(g1 + o);
                     f32x4_t dgam, dbet;
@@ -401,10 +401,14 @@ int run_reduce(const void* x, const void* dh, const void* h, const void* g1, con
     dim3 grid(sg.nchunks, G);
     if (MODE == 0 && vec_geom_ok<T>(C))
         hipLaunchKernelGGL((stats_stage1_vec<T, 4>), grid, dim3(NTHR), 0, st, (const T*)x, (float*)partial, P, C, sg.chunk);
+    else if (MODE == 1 && h == nullptr)
+        hipLaunchKernelGGL((reduce_stage1<T, MODE, false>), grid, dim3(NTHR), 0, st,
+                           (const T*)x, (const T*)dh, (const T*)h, (const T*)g1, mean, rstd, (T*)dgb,
+                           (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, act, slope);
     else
-    hipLaunchKernelGGL((reduce_stage1<T, MODE>), grid, dim3(NTHR), 0, st,
-                       (const T*)x, (const T*)dh, (const T*)h, (const T*)g1, mean, rstd, (T*)dgb,
-                       (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, act, slope);
+        hipLaunchKernelGGL((reduce_stage1<T, MODE, true>), grid, dim3(NTHR), 0, st,
+                           (const T*)x, (const T*)dh, (const T*)h, (const T*)g1, mean, rstd, (T*)dgb,
+                           (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, act, slope);
     MG_CHECK_LAUNCH("reduce_stage1");
     dim3 grid2((2 * C + 31) / 32, G);
     hipLaunchKernelGGL(reduce_stage2, grid2, dim3(256), 0, st, (const float*)partial, sums, sg.nchunks, 2 * C);
