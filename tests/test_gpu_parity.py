@@ -114,6 +114,37 @@ def test_generator_fp32_matches_oracle_odd_crop_with_gradients(hip_backend):
         assert err <= 5e-3 * max(g.abs().max().item(), 1e-6), (k, err, g.abs().max().item())
 
 
+def test_discriminator_fp32_matches_oracle_odd_crop_with_input_gradient(hip_backend):
+    """The discriminator pyramid at 320x320 (161 / 81 / 41 / 42 / 43-pixel maps, then the 160-pixel scale): forward and
+    the gradient w.r.t. its input (what the generator receives) against the oracle restatement."""
+    from michigan_amd import networks
+    from michigan_amd.synth import synth_state_dict
+    from oracle import michigan_oracle as O
+    opt = PU.small_opt(ndf=16, crop_size=320)
+    D = networks.MultiscaleDiscriminator(opt).train()
+    sd = synth_state_dict(D.state_dict(), seed=9, gain=1.0)
+    D.load_state_dict(sd)
+    D.cuda()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(4, 7, 320, 320, generator=g)
+    xg = x.clone().cuda().requires_grad_()
+    outs = D(xg)
+    xr = x.clone().requires_grad_()
+    refs = O.multiscale_discriminator(xr, sd, True, {})
+    loss = loss_r = 0
+    for po, pr in zip(outs, refs):
+        assert len(po) == len(pr)
+        for i, (a, b) in enumerate(zip(po, pr)):
+            assert tuple(a.shape) == tuple(b.shape)
+            assert (a.float().cpu() - b.detach()).abs().max().item() <= 1e-3 * max(1.0, b.abs().max().item()), i
+            w = torch.randn(b.shape, generator=g)
+            loss = loss + (a.float() * w.cuda()).sum()
+            loss_r = loss_r + (b * w).sum()
+    (gx,) = torch.autograd.grad(loss, xg)
+    (gr,) = torch.autograd.grad(loss_r, xr)
+    assert (gx.cpu() - gr).abs().max().item() <= 5e-3 * gr.abs().max().item()
+
+
 def test_train_step_runs_and_updates(hip_backend):
     """One generator + one discriminator step of the trainer at the golden size, bf16: finite losses,
     parameters move, discriminator untouched by the generator step."""
