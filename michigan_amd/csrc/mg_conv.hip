@@ -20,6 +20,7 @@ int g_mg_conv_halo_big = 1;      // 128 channels x 16x16 pixel halo tiles where 
 int g_mg_conv_halo = 1;          // 3x3 stride-1 convs on the LDS halo-tile kernel (mg_set_option(2, v))
 int g_mg_conv_bigtiles = 1;      // allow the 128x256 / 256x256 tiles (mg_set_option(1, v))
 extern int g_mg_wgrad3x3;          // mg_wgrad.hip (mg_set_option(3, v))
+extern int g_mg_conv_thin;         // mg_conv_thin.hip (mg_set_option(6, v))
 int g_mg_conv_pipeline = 1;      // 0 = register-staged double buffer, 1 = LDS-DMA 3-stage ring (mg_set_option(0, v))
 
 #include "mg_conv_common.h"
@@ -513,6 +514,7 @@ bool halo_applies(const ConvK& k)
 template <typename T>
 int dispatch_conv(ConvK& k, int epilogue, hipStream_t st)
 {
+    if (conv_thin_applies(k, ET<T>::DT, epilogue)) return launch_conv_thin(k, st);
     if (halo_applies<T>(k)) return launch_conv_halo(k, ET<T>::DT, epilogue, st);
     return epilogue == MG_EPI_SPADE ? dispatch_tiles<T, MG_EPI_SPADE>(k, st) : dispatch_tiles<T, MG_EPI_PLAIN>(k, st);
 }
@@ -564,5 +566,6 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 3 && (value == 0 || value == 1)) { g_mg_wgrad3x3 = value; return MG_OK; }
     if (key == 4 && (value == 0 || value == 1)) { g_mg_conv_halo_big = value; return MG_OK; }
     if (key == 5 && (value == 0 || value == 1)) { g_mg_conv_splitk = value; return MG_OK; }
+    if (key == 6 && (value == 0 || value == 1)) { g_mg_conv_thin = value; return MG_OK; }
     return mg_fail(MG_ERR_ARG, "mg_set_option: unknown key/value %d/%d", key, value);
 }

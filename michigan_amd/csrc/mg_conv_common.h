@@ -399,3 +399,5 @@ struct LinearPixMap {
 }  // namespace
 
 int launch_conv_halo(ConvK& k, int dtype, int epilogue, hipStream_t st);   // mg_conv_halo.hip
+bool conv_thin_applies(const ConvK& k, int dtype, int epilogue);            // mg_conv_thin.hip
+int launch_conv_thin(ConvK& k, hipStream_t st);

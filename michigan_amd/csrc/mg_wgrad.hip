@@ -299,6 +299,15 @@ extern "C" int mg_conv_wgrad(const mg_wgrad_desc* d, void* stream)
     for (int t = 0; t < MG_MAX_TAPS; ++t)
         k.tap[t] = t < d->ntaps ? (int)((((uint32_t)(int)d->tap_dy[t]) & 0xffffu) | (((uint32_t)(int)d->tap_dx[t]) << 16)) : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == MG_BF16 && d->ntaps == 9 && d->isy == 1 && d->isx == 1 && d->Hin == d->Hj && d->Win == d->Wj && d->Cin == 8) {
+        bool std3x3 = true;
+        for (int t = 0; t < 9; ++t) std3x3 = std3x3 && d->tap_dy[t] == t / 3 - 1 && d->tap_dx[t] == t % 3 - 1;
+        Wg3K k3;
+        k3.x = d->x; k3.dy = d->dy; k3.dw = d->dw; k3.dbias = d->dbias;
+        k3.N = d->N; k3.H = d->Hin; k3.W = d->Win; k3.Cin = d->Cin; k3.Cg = d->Cg;
+        k3.nstg = 0; k3.sps = 0; k3.tiles_m = k3.tiles_n = 0; k3.splitk = 0;
+        if (std3x3 && wgrad_thin_applies(k3)) return launch_wgrad_thin(k3, st);
+    }
     if (g_mg_wgrad3x3 && d->dtype == MG_BF16 && (d->flags & 1) && d->ntaps == 9 && d->isy == 1 && d->isx == 1 &&
         d->Hin == d->Hj && d->Win == d->Wj && (d->Win == 16 || d->Win % 32 == 0) && (d->Hin * d->Win) % 32 == 0 &&
         d->Cin >= 64 && d->Cg >= 64) {

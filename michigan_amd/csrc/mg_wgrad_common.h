@@ -13,3 +13,5 @@ struct Wg3K {
 };
 
 int launch_wgrad3x3(Wg3K& k, hipStream_t st);   // mg_wgrad3x3.hip
+bool wgrad_thin_applies(const Wg3K& k);           // mg_conv_thin.hip: 8-channel X, 64 / 128-channel dY
+int launch_wgrad_thin(Wg3K& k, hipStream_t st);

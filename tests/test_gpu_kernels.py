@@ -446,6 +446,57 @@ def test_halo_conv_ragged_geometry(cin, cout, H, W, big, dt):
     _close(f"halo ragged dx {dt}", dx, dxr.permute(0, 2, 3, 1), 5e-5 if dt == "f32" else TOL[dt])
 
 
+@pytest.mark.parametrize("cout,H,W,act,with_bias", [(128, 72, 64, "relu", True), (64, 45, 96, "lrelu", False),
+                                                     (96, 128, 32, "none", True), (128, 61, 128, "relu", True)], ids=str)
+def test_thin_conv_8_channel_input(cout, H, W, act, with_bias):
+    """The register-weight kernel for 3x3 convs over an 8-channel bf16 map (SPADE's mlp_shared): heights that are not
+    multiples of its 8-row tile, 64 / 96 / 128 output channels, every fused activation, against torch's fp32 convolution
+    and against the tap-list kernel it replaces (mg_set_option(6, 0))."""
+    from michigan_amd import ops, _cabi
+    g = torch.Generator().manual_seed(cout + H)
+    x = torch.randn(4, H, W, 8, generator=g).bfloat16().cuda()
+    w = (torch.randn(cout, 8, 3, 3, generator=g) / 8).cuda()
+    b = torch.randn(cout, generator=g).cuda() if with_bias else None
+    code = {"relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "none": ops.ACT_NONE}[act]
+    be = _cabi.backend()
+    y = ops.conv2d(x, w, b, padding=1, act=code)
+    be.mg_set_option(6, 0)
+    try:
+        y_taps = ops.conv2d(x, w, b, padding=1, act=code)
+    finally:
+        be.mg_set_option(6, 1)
+    yr = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.bfloat16().float(), b, padding=1)
+    yr = {"relu": torch.relu, "lrelu": lambda t: torch.nn.functional.leaky_relu(t, 0.2), "none": lambda t: t}[act](yr)
+    _close("thin conv vs torch", y, yr.permute(0, 2, 3, 1), TOL["bf16"])
+    _close("thin conv vs tap-list kernel", y, y_taps, TOL["bf16"])
+
+
+@pytest.mark.parametrize("cg,H,W,want_bias", [(128, 72, 64, True), (64, 45, 96, True), (128, 61, 128, False), (64, 128, 32, True)], ids=str)
+def test_thin_wgrad_8_channel_input(cg, H, W, want_bias):
+    """Weight (and bias) gradient of the same layers: register-accumulator kernel vs torch's fp32 autograd on the same
+    bf16 operands and vs the generic kernel (mg_set_option(6, 0)); heights that are not multiples of its 4-row tile."""
+    from michigan_amd import ops, _cabi
+    g = torch.Generator().manual_seed(cg + H)
+    x = torch.randn(4, H, W, 8, generator=g).bfloat16().cuda()
+    dy = torch.randn(4, H, W, cg, generator=g).bfloat16().cuda()
+    be = _cabi.backend()
+    res = ops.conv_wgrad(x, dy, 3, 3, 1, 1, want_bias=want_bias)
+    be.mg_set_option(6, 0)
+    try:
+        res_taps = ops.conv_wgrad(x, dy, 3, 3, 1, 1, want_bias=want_bias)
+    finally:
+        be.mg_set_option(6, 1)
+    w = torch.zeros(cg, 8, 3, 3, device="cuda", requires_grad=True)
+    b = torch.zeros(cg, device="cuda", requires_grad=True)
+    torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w, b, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    dw_ref = w.grad.permute(2, 3, 0, 1).reshape(9, cg, 8)
+    dw, dw_taps = (res[0], res_taps[0]) if want_bias else (res, res_taps)
+    _close("thin wgrad vs torch", dw, dw_ref, 1e-4)
+    _close("thin wgrad vs generic kernel", dw, dw_taps, 1e-4)
+    if want_bias:
+        _close("thin dbias vs torch", res[1], b.grad, 1e-4)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("C,H,W", [(64, 200, 176), (136, 97, 131)], ids=str)
 def test_spade_halo_ragged_geometry(C, H, W, dt):
