@@ -249,6 +249,45 @@ int mg_sn_scale(const float* w, const float* sigma, float* out, int64_t numel, v
 int mg_sn_bwd(const float* g, const float* u, const float* v, const float* s, const float* sigma, float* out,
               int32_t rows, int32_t cols, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Input pipeline on the device: the per-sample work the reference does with
+ * PIL / numpy / cv2 in loader worker processes, from decoded u8 maps to the float tensors of the `data` dict.
+ * Byte / index outputs are bit-exact restatements; all maps are dense, u8 sources are HWC as PIL decodes them.
+ *
+ * mg_input_crop_u8: resize(NEAREST, optional) + random crop + horizontal flip + ToTensor of get_transform
+ *   (data/base_dataset.py:419-456) for a batch: dst[n][c][y][x] = conv(src[n][ytab[y0+y]][xtab[x0 + (flip ? W-1-x : x)]][c])
+ *   with crop[n] = {x0, y0, flip} (device int32, get_params base_dataset.py:398-416), src u8 [N][Hs][Ws][C], dst fp32
+ *   NCHW [N][C][H][W]; ytab / xtab (device int32 [load_h] / [load_w], NULL = identity) hold Pillow's nearest-neighbour
+ *   source index per load-size coordinate (mg_nearest_table).  mode 0 (images): (v/255 - 0.5)/0.5 = ToTensor +
+ *   Normalize(0.5, 0.5) -- images must already be at load size (bicubic resampling is decode-side work); mode 1 (label,
+ *   orientation and hole maps, pix2pix_dataset.py:72-73,117,146-147): (v/255)*255 and, when unknown_label >= 0, 255 ->
+ *   unknown_label; mode 2: v/255 (the RGB orientation image, :127).  mul (optional, fp32 [N][1][H][W]) multiplies every
+ *   channel ("* label_tensor", :127,133).  The float operations are single IEEE operations in the reference's order.
+ * mg_onehot_labels: preprocess_input's FloatTensor(bs, nc, h, w).zero_().scatter_(1, label.long(), 1.0)
+ *   (models/pix2pix_model.py:231-246); label fp32 [N][1][HW], out fp32 [N][nc][HW]; indices outside [0, nc) set nothing.
+ * mg_orient_to_rgb_u8: trans_orient_to_rgb (base_dataset.py:363-385): out u8 [npix][3] = np.uint8(((cos 2t + 1)/2,
+ *   (sin 2t + 1)/2, 0.5) * label * 255), t = orient/255*pi; `table` = device copy of mg_orient_rgb_table's 256x3 doubles.
+ * mg_generate_hole_u8: generate_hole (base_dataset.py:335-361), one sample per workgroup: th[n] = the
+ *   random.uniform(0.5, 1.2) draw, u[n] in [0,1) selects the centre among the non-zero pixels of orient_mask
+ *   (center_idx = min(int(u * nums), nums - 1), row-major order as np.where lists them); hole u8 [N][H][W];
+ *   info (optional, device int32 [N][4]) receives {nums, centre row, centre column, rr}.
+ * mg_noise_octaves: generate_noise (base_dataset.py:387-396): out fp32 NCHW [N][3][S][S] = (sum over octaves o of
+ *   cv2.resize(field_o, (S, S), INTER_LINEAR)) / n_octaves, fields = float64 Gaussian draws, per sample the octaves
+ *   back to back, octave o = [S>>o][S>>o][3] while S>>o >= 8 (mg_noise_field_len(S) doubles per sample).
+ * Host helpers (no GPU): mg_nearest_table fills table[dst] with Pillow's source index walk; mg_orient_rgb_table fills
+ *   256x3 doubles; mg_noise_field_len returns the per-sample field length. */
+int mg_input_crop_u8(const uint8_t* src, float* dst, const int32_t* crop, const int32_t* ytab, const int32_t* xtab,
+                     const float* mul, int32_t N, int32_t Hs, int32_t Ws, int32_t C, int32_t H, int32_t W,
+                     int32_t mode, int32_t unknown_label, void* stream);
+int mg_onehot_labels(const float* label, float* out, int32_t N, int64_t HW, int32_t nc, void* stream);
+int mg_orient_to_rgb_u8(const uint8_t* orient, const uint8_t* label, const double* table, uint8_t* out, int64_t npix, void* stream);
+int mg_generate_hole_u8(const uint8_t* mask, const uint8_t* orient_mask, const double* th, const double* u,
+                        uint8_t* hole, int32_t* info, int32_t N, int32_t H, int32_t W, void* stream);
+int mg_noise_octaves(const double* fields, float* out, int32_t N, int32_t S, void* stream);
+int     mg_nearest_table(int32_t src, int32_t dst, int32_t* table);
+int     mg_orient_rgb_table(double* table);
+int64_t mg_noise_field_len(int32_t S);
+
 /* Hardware probes used by the test-suite (MFMA / ds_read_tr fragment maps). */
 int mg_probe_mfma_layout(float* out /* [3][64][16] */, void* stream);
 int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* out /* [64][4] */, void* stream);

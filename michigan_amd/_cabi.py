@@ -76,6 +76,14 @@ _PROTOS = {
     "mg_sn_scale": ([_vp, _vp, _vp, _i64, _vp], _i32),
     "mg_sn_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp], _i32),
     "mg_adam_step": ([_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp], _i32),
+    "mg_input_crop_u8": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "mg_onehot_labels": ([_vp, _vp, _i32, _i64, _i32, _vp], _i32),
+    "mg_orient_to_rgb_u8": ([_vp, _vp, _vp, _vp, _i64, _vp], _i32),
+    "mg_generate_hole_u8": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
+    "mg_noise_octaves": ([_vp, _vp, _i32, _i32, _vp], _i32),
+    "mg_nearest_table": ([_i32, _i32, _vp], _i32),
+    "mg_orient_rgb_table": ([_vp], _i32),
+    "mg_noise_field_len": ([_i32], _i64),
     "mg_probe_mfma_layout": ([_vp, _vp], _i32),
     "mg_probe_tr16": ([_vp, _vp, _vp], _i32),
     "mg_set_option": ([_i32, _i32], _i32),
@@ -84,7 +92,7 @@ _PROTOS = {
     "mg_last_error": ([], ctypes.c_char_p),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
-_NO_STATUS = {"mg_stats_workspace", "mg_sizeof_desc", "mg_abi_version", "mg_last_error"}
+_NO_STATUS = {"mg_stats_workspace", "mg_sizeof_desc", "mg_abi_version", "mg_last_error", "mg_noise_field_len"}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmichigan_hip.so")
 

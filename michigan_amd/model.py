@@ -21,7 +21,7 @@ from typing import Dict
 import torch
 import torch.nn as nn
 
-from . import networks, parallel
+from . import inputs, networks, parallel
 from .optim import FlatAdam
 
 
@@ -81,9 +81,8 @@ class Pix2PixModel(nn.Module):
                 out[k] = data[k].to(dev, non_blocking=True)
         for src, dst in (("label_tag", "input_tag"), ("label_ref", "input_ref")):
             if dst not in out:
-                lab = data[src].long().to(dev)
                 nc = self.opt.label_nc + (1 if self.opt.contain_dontcare_label else 0)
-                out[dst] = torch.zeros(lab.shape[0], nc, lab.shape[2], lab.shape[3], device=dev).scatter_(1, lab, 1.0)
+                out[dst] = inputs.onehot_labels(data[src].to(dev), nc)        # zeros().scatter_(1, label.long(), 1.0)
         return out
 
     def orientation_planes(self, d):

@@ -431,3 +431,74 @@ class EmulatorBackend:
         denom = vv.sqrt() / math.sqrt(bc2) + eps
         p.addcdiv_(mm, denom, value=-lr / bc1)
         return 0
+
+    # -- input pipeline: the contract is the reference restatement in oracle/inputs_oracle.py --
+    def mg_input_crop_u8(self, src, dst, crop, ytab, xtab, mul, N, Hs, Ws, C, H, W, mode, unknown_label, stream=None):
+        from oracle import inputs_oracle as IO
+        cr = _view(crop, (N, 3), torch.int32).numpy()
+        yt = None if _addr(ytab) == 0 else _view(ytab, (int(cr[:, 1].max()) + H,), torch.int32).numpy()
+        xt = None if _addr(xtab) == 0 else _view(xtab, (int(cr[:, 0].max()) + W,), torch.int32).numpy()
+        m = None if _addr(mul) == 0 else _view(mul, (N, 1, H, W), torch.float32).numpy()
+        out = IO.crop_flip_to_tensor(_view(src, (N, Hs, Ws, C), torch.uint8).numpy(), cr, H, W, mode, unknown_label, yt, xt, m)
+        _view(dst, (N, C, H, W), torch.float32)[:] = torch.from_numpy(out)
+        return 0
+
+    def mg_onehot_labels(self, label, out, N, HW, nc, stream=None):
+        from oracle import inputs_oracle as IO
+        lab = _view(label, (N, 1, HW), torch.float32).numpy()
+        _view(out, (N, nc, HW), torch.float32)[:] = torch.from_numpy(IO.onehot_labels(lab, nc))
+        return 0
+
+    def mg_orient_to_rgb_u8(self, orient, label, table, out, npix, stream=None):
+        from oracle import inputs_oracle as IO
+        o = _view(orient, (1, npix), torch.uint8).numpy()
+        l = _view(label, (1, npix), torch.uint8).numpy()
+        _view(out, (1, npix, 3), torch.uint8)[:] = torch.from_numpy(IO.trans_orient_to_rgb(o, l))
+        return 0
+
+    def mg_generate_hole_u8(self, mask, orient_mask, th, u, hole, info, N, H, W, stream=None):
+        from oracle import inputs_oracle as IO
+        mk = _view(mask, (N, H, W), torch.uint8).numpy()
+        om = _view(orient_mask, (N, H, W), torch.uint8).numpy()
+        thv, uv = _view(th, (N,), torch.float64), _view(u, (N,), torch.float64)
+        out = _view(hole, (N, H, W), torch.uint8)
+        inf = None if _addr(info) == 0 else _view(info, (N, 4), torch.int32)
+        for n in range(N):
+            nums = int((om[n] != 0).sum())
+            ci = IO.hole_center_index(float(uv[n]), nums) if nums else 0
+            out[n] = torch.from_numpy(IO.generate_hole(mk[n], om[n], float(thv[n]), ci))
+            if inf is not None:
+                if nums:
+                    ys, xs = (om[n] != 0).nonzero()
+                    inf[n] = torch.tensor([nums, int(ys[ci]), int(xs[ci]), int(int(float(thv[n]) * nums) / math.pi)], dtype=torch.int32)
+                else:
+                    inf[n] = torch.tensor([0, -1, -1, 0], dtype=torch.int32)
+        return 0
+
+    def mg_noise_octaves(self, fields, out, N, S, stream=None):
+        from oracle import inputs_oracle as IO
+        sizes = IO.noise_octave_sizes(S)
+        per = sum(s * s * 3 for s in sizes)
+        fv = _view(fields, (N, per), torch.float64).numpy()
+        o = _view(out, (N, 3, S, S), torch.float32)
+        for n in range(N):
+            fl, off = [], 0
+            for s in sizes:
+                fl.append(fv[n, off:off + s * s * 3].reshape(s, s, 3))
+                off += s * s * 3
+            o[n] = torch.from_numpy(IO.generate_noise_from_fields(fl, S)).permute(2, 0, 1)
+        return 0
+
+    def mg_nearest_table(self, src, dst, table):
+        from oracle import inputs_oracle as IO
+        _view(table, (dst,), torch.int32)[:] = torch.from_numpy(IO.pil_nearest_table(src, dst))
+        return 0
+
+    def mg_orient_rgb_table(self, table):
+        from oracle import inputs_oracle as IO
+        _view(table, (256, 3), torch.float64)[:] = torch.from_numpy(IO.orient_rgb_table())
+        return 0
+
+    def mg_noise_field_len(self, S):
+        from oracle import inputs_oracle as IO
+        return sum(s * s * 3 for s in IO.noise_octave_sizes(S))
