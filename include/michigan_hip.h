@@ -259,7 +259,7 @@ int mg_sn_bwd(const float* g, const float* u, const float* v, const float* s, co
  *   with crop[n] = {x0, y0, flip} (device int32, get_params base_dataset.py:398-416), src u8 [N][Hs][Ws][C], dst fp32
  *   NCHW [N][C][H][W]; ytab / xtab (device int32 [load_h] / [load_w], NULL = identity) hold Pillow's nearest-neighbour
  *   source index per load-size coordinate (mg_nearest_table).  mode 0 (images): (v/255 - 0.5)/0.5 = ToTensor +
- *   Normalize(0.5, 0.5) -- images must already be at load size (bicubic resampling is decode-side work); mode 1 (label,
+ *   Normalize(0.5, 0.5) -- images come at load size (mg_resize_bicubic_u8 brings them there); mode 1 (label,
  *   orientation and hole maps, pix2pix_dataset.py:72-73,117,146-147): (v/255)*255 and, when unknown_label >= 0, 255 ->
  *   unknown_label; mode 2: v/255 (the RGB orientation image, :127).  mul (optional, fp32 [N][1][H][W]) multiplies every
  *   channel ("* label_tensor", :127,133).  The float operations are single IEEE operations in the reference's order.
@@ -284,6 +284,16 @@ int mg_orient_to_rgb_u8(const uint8_t* orient, const uint8_t* label, const doubl
 int mg_generate_hole_u8(const uint8_t* mask, const uint8_t* orient_mask, const double* th, const double* u,
                         uint8_t* hole, int32_t* info, int32_t N, int32_t H, int32_t W, void* stream);
 int mg_noise_octaves(const double* fields, float* out, int32_t N, int32_t S, void* stream);
+/* mg_resize_bicubic_u8: transforms.Resize(osize, Image.BICUBIC) on u8 images (base_dataset.py:421-424; arithmetic =
+ *   Pillow Resample.c, 8 bits per channel): horizontal pass src [N][Hs][Ws][C] -> tmp [N][Hs][Wd][C], vertical pass ->
+ *   dst [N][Hd][Wd][C]; x/y bounds (device int32 [out][2] = first source index, count) and 22-bit fixed-point
+ *   coefficients (device int32 [out][k]) are copies of mg_bicubic_table's host output, k = mg_bicubic_ksize(in, out). */
+int mg_resize_bicubic_u8(const uint8_t* src, uint8_t* tmp, uint8_t* dst, const int32_t* xbounds, const int32_t* xcoef, int32_t kx,
+                         const int32_t* ybounds, const int32_t* ycoef, int32_t ky, int32_t N, int32_t Hs, int32_t Ws,
+                         int32_t Hd, int32_t Wd, int32_t C, void* stream);
+int     mg_inputs_set_option(int32_t key, int32_t value);   /* key 0: 1 = LDS-tiled noise kernel (default), 0 = per-pixel gather form; same results */
+int     mg_bicubic_ksize(int32_t in_size, int32_t out_size);
+int     mg_bicubic_table(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* coef);
 int     mg_nearest_table(int32_t src, int32_t dst, int32_t* table);
 int     mg_orient_rgb_table(double* table);
 int64_t mg_noise_field_len(int32_t S);

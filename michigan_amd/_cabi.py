@@ -81,6 +81,10 @@ _PROTOS = {
     "mg_orient_to_rgb_u8": ([_vp, _vp, _vp, _vp, _i64, _vp], _i32),
     "mg_generate_hole_u8": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp], _i32),
     "mg_noise_octaves": ([_vp, _vp, _i32, _i32, _vp], _i32),
+    "mg_resize_bicubic_u8": ([_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "mg_bicubic_ksize": ([_i32, _i32], _i32),
+    "mg_inputs_set_option": ([_i32, _i32], _i32),
+    "mg_bicubic_table": ([_i32, _i32, _vp, _vp], _i32),
     "mg_nearest_table": ([_i32, _i32, _vp], _i32),
     "mg_orient_rgb_table": ([_vp], _i32),
     "mg_noise_field_len": ([_i32], _i64),
@@ -92,7 +96,7 @@ _PROTOS = {
     "mg_last_error": ([], ctypes.c_char_p),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
-_NO_STATUS = {"mg_stats_workspace", "mg_sizeof_desc", "mg_abi_version", "mg_last_error", "mg_noise_field_len"}
+_NO_STATUS = {"mg_stats_workspace", "mg_sizeof_desc", "mg_abi_version", "mg_last_error", "mg_noise_field_len", "mg_bicubic_ksize"}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmichigan_hip.so")
 

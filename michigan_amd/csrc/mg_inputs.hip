@@ -198,6 +198,112 @@ __global__ void noise_kernel(const double* __restrict__ fields, float* __restric
     }
 }
 
+// Tiled form of the same arithmetic: a workgroup owns a 32 x 8 pixel tile of one sample (128-byte output rows per
+// channel plane) and first stages, for every octave below full size, the few source texels its pixels interpolate
+// between ((32 >> o) + 3) x ((8 >> o) + 3) at most) into LDS -- the per-pixel kernel above issues 72 gathered 8-byte
+// loads per pixel through the vector L1; here each field value is fetched once per tile and the taps are LDS reads.
+// Octaves whose patch does not fit the LDS budget (only possible for non power-of-two sizes) read global memory.
+constexpr int NT_W = 32, NT_H = 8, NT_MAXTEX = 448, NT_MAXOCT = 16;
+__global__ __launch_bounds__(NT_W * NT_H)
+void noise_tiled_kernel(const double* __restrict__ fields, float* __restrict__ out, int N, int S, int noct, int64_t per_sample,
+                        int tiles_x, int tiles_y)
+{
+    __shared__ double s_tex[NT_MAXTEX * 3];
+    __shared__ int s_meta[NT_MAXOCT][5];                      // LDS offset (texels, -1 = not staged), x0, y0, patch width, patch height
+    const int tile = blockIdx.x % (tiles_x * tiles_y), b = blockIdx.x / (tiles_x * tiles_y);
+    const int X0 = (tile % tiles_x) * NT_W, Y0 = (tile / tiles_x) * NT_H;
+    const int X1 = min(X0 + NT_W, S) - 1, Y1 = min(Y0 + NT_H, S) - 1;
+    const double* fb = fields + (size_t)b * per_sample;
+    const float wsum = (float)noct;
+    for (int t = threadIdx.x; t < 1; t += blockDim.x) {       // one thread lays out the patches (a dozen integers)
+        int used = 0;
+        for (int o = 1; o < noct && o < NT_MAXOCT; ++o) {
+            const int s = S >> o;
+            const double scale = 1.0 / ((double)S / (double)s);
+            const int x0 = cv_linear_x(X0, s, scale).i0, x1 = cv_linear_x(X1, s, scale).i1;
+            const int y0 = cv_linear_y(Y0, s, scale).i0, y1 = cv_linear_y(Y1, s, scale).i1;
+            const int pw = x1 - x0 + 1, ph = y1 - y0 + 1;
+            const bool fits = used + pw * ph <= NT_MAXTEX;
+            s_meta[o][0] = fits ? used : -1; s_meta[o][1] = x0; s_meta[o][2] = y0; s_meta[o][3] = pw; s_meta[o][4] = ph;
+            if (fits) used += pw * ph;
+        }
+    }
+    __syncthreads();
+    {
+        const double* f = fb + (size_t)S * S * 3;
+        for (int o = 1; o < noct && o < NT_MAXOCT; ++o) {
+            const int s = S >> o, off = s_meta[o][0], x0 = s_meta[o][1], y0 = s_meta[o][2], pw = s_meta[o][3], ph = s_meta[o][4];
+            if (off >= 0)
+                for (int e = threadIdx.x; e < pw * ph * 3; e += blockDim.x) {
+                    const int c = e % 3, px = (e / 3) % pw, py = e / (3 * pw);
+                    s_tex[off * 3 + e] = f[((size_t)(y0 + py) * s + (x0 + px)) * 3 + c];
+                }
+            f += (size_t)s * s * 3;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < NT_W * NT_H; t += blockDim.x) {
+        const int x = X0 + t % NT_W, y = Y0 + t / NT_W;
+        if (x >= S || y >= S) continue;
+        float acc[3];
+        for (int c = 0; c < 3; ++c) acc[c] = (float)__dadd_rn(0.0, fb[((size_t)y * S + x) * 3 + c]);    // octave 0: same size, a copy
+        const double* f = fb + (size_t)S * S * 3;
+        for (int o = 1; o < noct; ++o) {
+            const int s = S >> o;
+            const double scale = 1.0 / ((double)S / (double)s);
+            const LinTap tx = cv_linear_x(x, s, scale), ty = cv_linear_y(y, s, scale);
+            const bool staged = o < NT_MAXOCT && s_meta[o][0] >= 0;
+            const double* r0; const double* r1; int i0 = tx.i0, i1 = tx.i1;
+            if (staged) {
+                const int off = s_meta[o][0], x0 = s_meta[o][1], y0 = s_meta[o][2], pw = s_meta[o][3];
+                r0 = s_tex + (size_t)(off + (ty.i0 - y0) * pw) * 3; r1 = s_tex + (size_t)(off + (ty.i1 - y0) * pw) * 3;
+                i0 -= x0; i1 -= x0;
+            } else { r0 = f + (size_t)ty.i0 * s * 3; r1 = f + (size_t)ty.i1 * s * 3; }
+            for (int c = 0; c < 3; ++c) {
+                double h0, h1;
+                if (i0 == i1) { h0 = r0[i0 * 3 + c]; h1 = r1[i0 * 3 + c]; }
+                else {
+                    h0 = __dadd_rn(__dmul_rn(r0[i0 * 3 + c], tx.w0), __dmul_rn(r0[i1 * 3 + c], tx.w1));
+                    h1 = __dadd_rn(__dmul_rn(r1[i0 * 3 + c], tx.w0), __dmul_rn(r1[i1 * 3 + c], tx.w1));
+                }
+                const double v = __dadd_rn(__dmul_rn(h0, ty.w0), __dmul_rn(h1, ty.w1));
+                acc[c] = (float)__dadd_rn((double)acc[c], v);
+            }
+            f += (size_t)s * s * 3;
+        }
+        for (int c = 0; c < 3; ++c) out[(((size_t)b * 3 + c) * S + y) * S + x] = __fdiv_rn(acc[c], wsum);
+    }
+}
+
+// ---- transforms.Resize(osize, Image.BICUBIC) on u8 images (base_dataset.py:421-424 -> Pillow Resample.c, 8 bits per channel):
+// two separable passes, horizontal first, each output = clip8((2^21 + sum_k src[first + k] * coef[k]) >> 22) with
+// the 22-bit fixed-point coefficients and [first, count) windows of mg_bicubic_table; the intermediate image is u8
+// like Pillow's.  Integer multiply-adds only: bit-exact by construction once the tables agree.
+template <bool HORIZ>
+__global__ void bicubic_pass_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const int32_t* __restrict__ bounds,
+                                    const int32_t* __restrict__ coef, int ksize, int N, int Hin, int Win, int Hout, int Wout, int C)
+{
+    const int64_t n = (int64_t)N * Hout * Wout;
+    GRID_STRIDE(i, n) {
+        const int x = (int)(i % Wout); int64_t p = i / Wout;
+        const int y = (int)(p % Hout); const int b = (int)(p / Hout);
+        const int o = HORIZ ? x : y;
+        const int first = bounds[o * 2], cnt = bounds[o * 2 + 1];
+        const int32_t* k = coef + (size_t)o * ksize;
+        const uint8_t* s = HORIZ ? src + (((size_t)b * Hin + y) * Win + first) * C : src + (((size_t)b * Hin + first) * Win + x) * C;
+        const size_t step = HORIZ ? (size_t)C : (size_t)Win * C;
+        int acc[4] = {1 << 21, 1 << 21, 1 << 21, 1 << 21};
+        for (int j = 0; j < cnt; ++j) {
+            const int w = k[j];
+            for (int c = 0; c < C; ++c) acc[c] += (int)s[j * step + c] * w;
+        }
+        for (int c = 0; c < C; ++c) {
+            int v = acc[c] >> 22;                              // arithmetic shift, then Pillow's clip8 table
+            dst[i * C + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
 }  // namespace
 
 // ---- host helpers (no GPU involved) --------------------------------------------------------------------------------
@@ -222,11 +328,62 @@ extern "C" int mg_orient_rgb_table(double* table)
     }
     return MG_OK;
 }
+// Pillow Resample.c: bicubic_filter (a = -0.5), precompute_coeffs, normalize_coeffs_8bpc
+static inline double mg_bicubic_filter(double x)
+{
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+extern "C" int mg_bicubic_ksize(int32_t in_size, int32_t out_size)
+{
+    if (in_size <= 0 || out_size <= 0) return -1;
+    double filterscale = (double)((float)in_size - 0.f) / out_size;
+    if (filterscale < 1.0) filterscale = 1.0;
+    return (int)ceil(2.0 * filterscale) * 2 + 1;
+}
+extern "C" int mg_bicubic_table(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* coef)
+{
+    MG_CHECK_ARG(in_size > 0 && out_size > 0 && bounds && coef, "mg_bicubic_table: bad arguments");
+    const int ksize = mg_bicubic_ksize(in_size, out_size);
+    MG_CHECK_ARG(ksize <= 256, "mg_bicubic_table: scale factor too large");
+    double scale = (double)((float)in_size - 0.f) / out_size, filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 2.0 * filterscale, ss = 1.0 / filterscale;
+    double k[256];
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = 0.f + (xx + 0.5) * scale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; ++x) { const double w = mg_bicubic_filter((x + xmin - center + 0.5) * ss); k[x] = w; ww += w; }
+        for (int x = 0; x < xmax; ++x) if (ww != 0.0) k[x] /= ww;
+        for (int x = 0; x < ksize; ++x) {
+            const double v = x < xmax ? k[x] : 0.0;
+            coef[(size_t)xx * ksize + x] = v < 0 ? (int)(-0.5 + v * (1 << 22)) : (int)(0.5 + v * (1 << 22));
+        }
+        bounds[xx * 2] = xmin; bounds[xx * 2 + 1] = xmax;
+    }
+    return MG_OK;
+}
 extern "C" int64_t mg_noise_field_len(int32_t S)
 {
     int64_t n = 0;
     for (int s = S; s >= 8; s /= 2) n += (int64_t)s * s * 3;
     return n;
+}
+
+static int g_noise_tiled = 1;                                  // A/B switch (tools/bench_inputs.py --per-pixel-noise)
+extern "C" int mg_inputs_set_option(int32_t key, int32_t value)
+{
+    MG_CHECK_ARG(key == 0, "mg_inputs_set_option: unknown key");
+    g_noise_tiled = value != 0;
+    return MG_OK;
 }
 
 // ---- launches ---------------------------------------------------------------------------------------------------------
@@ -279,8 +436,27 @@ extern "C" int mg_noise_octaves(const double* fields, float* out, int32_t N, int
     MG_CHECK_ARG(fields && out && N > 0 && S >= 8, "mg_noise_octaves: bad arguments");
     int noct = 0;
     for (int s = S; s >= 8; s /= 2) ++noct;                    // width //= 2 while >= 8: octave o has side S >> o
-    hipLaunchKernelGGL(noise_kernel, dim3(ew_grid((int64_t)N * S * S)), dim3(NTHR), 0, reinterpret_cast<hipStream_t>(stream),
-                       fields, out, N, S, noct, mg_noise_field_len(S));
+    const int tx = (S + NT_W - 1) / NT_W, ty = (S + NT_H - 1) / NT_H;
+    if (g_noise_tiled && (int64_t)N * tx * ty < (1ll << 31))
+        hipLaunchKernelGGL(noise_tiled_kernel, dim3((unsigned)(N * tx * ty)), dim3(NT_W * NT_H), 0, reinterpret_cast<hipStream_t>(stream),
+                           fields, out, N, S, noct, mg_noise_field_len(S), tx, ty);
+    else
+        hipLaunchKernelGGL(noise_kernel, dim3(ew_grid((int64_t)N * S * S)), dim3(NTHR), 0, reinterpret_cast<hipStream_t>(stream),
+                           fields, out, N, S, noct, mg_noise_field_len(S));
     MG_CHECK_LAUNCH("mg_noise_octaves");
+    return MG_OK;
+}
+
+extern "C" int mg_resize_bicubic_u8(const uint8_t* src, uint8_t* tmp, uint8_t* dst, const int32_t* xbounds, const int32_t* xcoef, int32_t kx,
+                                    const int32_t* ybounds, const int32_t* ycoef, int32_t ky, int32_t N, int32_t Hs, int32_t Ws,
+                                    int32_t Hd, int32_t Wd, int32_t C, void* stream)
+{
+    MG_CHECK_ARG(src && tmp && dst && xbounds && xcoef && ybounds && ycoef, "mg_resize_bicubic_u8: null pointer");
+    MG_CHECK_ARG(N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && C > 0 && C <= 4 && kx > 0 && ky > 0, "mg_resize_bicubic_u8: bad geometry");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bicubic_pass_kernel<true>, dim3(ew_grid((int64_t)N * Hs * Wd)), dim3(NTHR), 0, st, src, tmp, xbounds, xcoef, kx, N, Hs, Ws, Hs, Wd, C);
+    MG_CHECK_LAUNCH("mg_resize_bicubic_u8(horizontal)");
+    hipLaunchKernelGGL(bicubic_pass_kernel<false>, dim3(ew_grid((int64_t)N * Hd * Wd)), dim3(NTHR), 0, st, (const uint8_t*)tmp, dst, ybounds, ycoef, ky, N, Hs, Wd, Hd, Wd, C);
+    MG_CHECK_LAUNCH("mg_resize_bicubic_u8(vertical)");
     return MG_OK;
 }

@@ -11,6 +11,7 @@ same arithmetic runs here as HIP kernels of libmichigan_hip.so on u8 maps that w
     orient_to_rgb_u8   trans_orient_to_rgb
     generate_hole_u8   generate_hole
     generate_noise     generate_noise (multi-octave, cv2.resize INTER_LINEAR)
+    resize_bicubic_u8  get_transform's Resize(BICUBIC) for images (Pillow's 8-bit resampler)
 
 `DeviceInputPipeline` strings them together into the `data` dict of pix2pix_dataset.py:178-188.  The random
 DRAWS stay on the host and follow the reference (random.randint / random.random / random.uniform of a
@@ -55,6 +56,31 @@ def orient_rgb_table(device) -> torch.Tensor:
     host = torch.empty(256, 3, dtype=torch.float64)
     C.backend().mg_orient_rgb_table(_p(host))
     return host.to(device)
+
+
+def bicubic_table(in_size: int, out_size: int, device):
+    """Pillow's bicubic windows / 22-bit coefficients for one axis: (bounds [out,2], coef [out,k], k) on `device`."""
+    be = C.backend()
+    k = int(be.mg_bicubic_ksize(in_size, out_size))
+    bounds = torch.empty(out_size, 2, dtype=torch.int32)
+    coef = torch.empty(out_size, k, dtype=torch.int32)
+    be.mg_bicubic_table(in_size, out_size, _p(bounds), _p(coef))
+    return bounds.to(device), coef.to(device), k
+
+
+def resize_bicubic_u8(src: torch.Tensor, size, tables=None) -> torch.Tensor:
+    """transforms.Resize(osize, Image.BICUBIC) on u8 images [N,Hs,Ws,C] -> [N,H,W,C] (Pillow-exact, two passes)."""
+    src = _u8(src)
+    n, hs, ws, c = src.shape
+    h, w = (size, size) if isinstance(size, int) else size
+    if (h, w) == (hs, ws):
+        return src
+    xt, yt = tables if tables is not None else (bicubic_table(ws, w, src.device), bicubic_table(hs, h, src.device))
+    tmp = torch.empty((n, hs, w, c), dtype=torch.uint8, device=src.device)
+    dst = torch.empty((n, h, w, c), dtype=torch.uint8, device=src.device)
+    C.backend().mg_resize_bicubic_u8(_p(src), _p(tmp), _p(dst), _p(xt[0]), _p(xt[1]), xt[2], _p(yt[0]), _p(yt[1]), yt[2],
+                                     n, hs, ws, h, w, c, _stream(src))
+    return dst
 
 
 def crop_u8(src: torch.Tensor, crop: torch.Tensor, size, *, mode: int, unknown_label: int = -1,
@@ -143,8 +169,8 @@ def generate_noise(n: int, size: int, device, generator: Optional[torch.Generato
 
 class DeviceInputPipeline:
     """Pix2pixDataset.__getitem__ (step 1: reference == target, pix2pix_dataset.py:66-194) for a whole batch on the
-    device.  Inputs are the decoded bytes: images u8 [N,L,L,3] already at load size (bicubic resampling is decode-side
-    work), label / orientation maps u8 [N,Hs,Ws] at their stored size (nearest-resized to load size here)."""
+    device.  Inputs are the decoded bytes at their stored size: images u8 [N,Hs,Ws,3] (bicubic-resized to load size here,
+    Pillow-exact), label / orientation maps u8 [N,Hs,Ws] (nearest-resized)."""
 
     def __init__(self, opt, device, rng: Optional[_random.Random] = None, generator: Optional[torch.Generator] = None):
         self.opt, self.device = opt, torch.device(device)
@@ -155,6 +181,7 @@ class DeviceInputPipeline:
         self.flip = bool(getattr(opt, "isTrain", True)) and not bool(getattr(opt, "no_flip", False))
         self.table = orient_rgb_table(self.device)
         self._tabs: Dict[int, Optional[torch.Tensor]] = {}
+        self._btabs = {}
 
     def _tab(self, src: int):
         if src not in self._tabs:
@@ -176,8 +203,11 @@ class DeviceInputPipeline:
         opt, dev, cs = self.opt, self.device, self.crop_size
         image, label, orient = (t.to(dev) for t in (image, label, orient))
         n = image.shape[0]
-        if image.shape[1] != self.load_size or image.shape[2] != self.load_size:
-            raise ValueError("images must already be at load size")
+        if image.shape[1] != self.load_size or image.shape[2] != self.load_size:       # Resize(osize, BICUBIC), base_dataset.py:421-424
+            key = (image.shape[1], image.shape[2])
+            if key not in self._btabs:
+                self._btabs[key] = (bicubic_table(key[1], self.load_size, dev), bicubic_table(key[0], self.load_size, dev))
+            image = resize_bicubic_u8(image, self.load_size, self._btabs[key])
         crop = self.draw_params(n).to(dev)
         yt, xt = self._tab(label.shape[1]), self._tab(label.shape[2])
         unknown = int(opt.label_nc)

@@ -502,3 +502,25 @@ class EmulatorBackend:
     def mg_noise_field_len(self, S):
         from oracle import inputs_oracle as IO
         return sum(s * s * 3 for s in IO.noise_octave_sizes(S))
+
+    def mg_inputs_set_option(self, key, value):
+        return 0
+
+    def mg_bicubic_ksize(self, in_size, out_size):
+        from oracle import inputs_oracle as IO
+        return IO.pil_bicubic_table(in_size, out_size)[1].shape[1]
+
+    def mg_bicubic_table(self, in_size, out_size, bounds, coef):
+        from oracle import inputs_oracle as IO
+        b, c = IO.pil_bicubic_table(in_size, out_size)
+        _view(bounds, b.shape, torch.int32)[:] = torch.from_numpy(b)
+        _view(coef, c.shape, torch.int32)[:] = torch.from_numpy(c)
+        return 0
+
+    def mg_resize_bicubic_u8(self, src, tmp, dst, xb, xc, kx, yb, yc, ky, N, Hs, Ws, Hd, Wd, C, stream=None):
+        from oracle import inputs_oracle as IO
+        s = _view(src, (N, Hs, Ws, C), torch.uint8).numpy()
+        d = _view(dst, (N, Hd, Wd, C), torch.uint8)
+        for n in range(N):
+            d[n] = torch.from_numpy(IO.pil_bicubic_resize_u8(s[n], Hd, Wd))
+        return 0

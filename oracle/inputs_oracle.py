@@ -171,3 +171,56 @@ def onehot_labels(label: np.ndarray, nc: int) -> np.ndarray:
     for c in range(nc):
         out[:, c] = (idx[:, 0] == c)
     return out
+
+
+# ---- transforms.Resize(osize, Image.BICUBIC) on u8 images: Pillow's Resample.c, 8 bits per channel ------------------------
+def _bicubic_filter(x: float) -> float:
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_bicubic_table(in_size: int, out_size: int):
+    """precompute_coeffs + normalize_coeffs_8bpc: (bounds int32 [out, 2] = first index / count, coef int32 [out, ksize])."""
+    scale = float(np.float32(in_size) - np.float32(0)) / out_size
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / filterscale
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    coef = np.zeros((out_size, ksize), dtype=np.int32)
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        k = [_bicubic_filter((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for w in k:
+            ww += w
+        k = [(w / ww if ww != 0.0 else w) for w in k]
+        for x, w in enumerate(k):
+            coef[xx, x] = int(-0.5 + w * (1 << 22)) if w < 0 else int(0.5 + w * (1 << 22))
+        bounds[xx] = (xmin, xmax)
+    return bounds, coef
+
+
+def pil_bicubic_resize_u8(src: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """src uint8 [H, W, C] -> uint8 [out_h, out_w, C]: horizontal pass into a u8 image, then the vertical pass;
+    each value clip8((2^21 + sum src * coef) >> 22)."""
+    h, w, c = src.shape
+
+    def one_pass(img, bounds, coef, axis):
+        img = np.moveaxis(img, axis, 0).astype(np.int64)
+        out = np.empty((bounds.shape[0],) + img.shape[1:], dtype=np.uint8)
+        for o in range(bounds.shape[0]):
+            f, n = int(bounds[o, 0]), int(bounds[o, 1])
+            acc = (1 << 21) + np.tensordot(coef[o, :n].astype(np.int64), img[f:f + n], axes=(0, 0))
+            out[o] = np.clip(acc >> 22, 0, 255)
+        return np.moveaxis(out, 0, axis)
+    tmp = one_pass(src, *pil_bicubic_table(w, out_w), axis=1) if out_w != w else src
+    return one_pass(tmp, *pil_bicubic_table(h, out_h), axis=0) if out_h != h else tmp

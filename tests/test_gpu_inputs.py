@@ -70,6 +70,21 @@ def test_crop_flip_matches_oracle(geom, mode):
     assert torch.equal(hip.cpu(), ref), f"crop mode {mode}: max diff {(hip.cpu() - ref).abs().max().item():.3e}"
 
 
+@pytest.mark.parametrize("geom", [(2, 64, 64, 71, 71, 3), (1, 50, 40, 37, 64, 1), (2, 96, 96, 40, 40, 3), (1, 512, 512, 568, 568, 3)], ids=str)
+def test_bicubic_resize_matches_oracle(geom):
+    from michigan_amd import inputs
+    n, hs, ws, hd, wd, c = geom
+    src = torch.randint(0, 256, (n, hs, ws, c), generator=torch.Generator().manual_seed(hs + wd), dtype=torch.uint8)
+    src[:, :4, :4] = 255
+    src[:, 4:8, :4] = 0
+    hip, ref = _both(lambda s, dev: inputs.resize_bicubic_u8(s, (hd, wd)), (src,))
+    assert torch.equal(hip.cpu(), ref)
+    if os.environ.get("MG_TEST_DRYRUN") != "1" and c == 3:
+        from PIL import Image                          # the reference's own call, on the box
+        want = torch.from_numpy(np.asarray(Image.fromarray(src[0].numpy()).resize((wd, hd), Image.BICUBIC)).copy())
+        assert torch.equal(hip[0].cpu(), want)
+
+
 def test_onehot_matches_oracle():
     from michigan_amd import inputs
     lab = _mask(3, 37, 53, 1)[:, None].float()
@@ -115,7 +130,7 @@ def test_generate_hole_empty_orientation_mask():
     assert torch.equal(hip.cpu(), ref) and int(ref.sum()) == 0
 
 
-@pytest.mark.parametrize("size,n", [(64, 2), (40, 1), (100, 1), (128, 2)])
+@pytest.mark.parametrize("size,n", [(64, 2), (40, 1), (100, 1), (72, 1), (128, 2)])
 def test_noise_octaves_match_oracle(size, n):
     from michigan_amd import inputs
     from oracle import inputs_oracle as IO
@@ -124,6 +139,23 @@ def test_noise_octaves_match_oracle(size, n):
     hip, ref = _both(lambda f, dev: inputs.noise_from_fields(f, size), (fields,))
     err = (hip.cpu() - ref).abs().max().item()
     assert err <= 1e-6, f"noise {size}: max abs err {err:.3e}"
+
+
+def test_noise_tiled_equals_per_pixel_kernel_at_512():
+    """The LDS-tiled kernel and the per-pixel gather kernel are the same arithmetic: bit-identical at the full size."""
+    from michigan_amd import inputs, _cabi
+    be = _cabi.backend()
+    assert be.name == "hip"
+    fields = torch.randn(2, inputs.noise_field_len(512), dtype=torch.float64, device="cuda",
+                         generator=torch.Generator(device="cuda").manual_seed(9)) * 0.25 + 0.5
+    tiled = inputs.noise_from_fields(fields, 512)
+    be.mg_inputs_set_option(0, 0)
+    try:
+        gather = inputs.noise_from_fields(fields, 512)
+    finally:
+        be.mg_inputs_set_option(0, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(tiled, gather)
 
 
 def test_noise_fullsize_properties():
@@ -158,7 +190,7 @@ def test_pipeline_fullsize_on_device():
     label = _mask(n, 512, 512, 12)
     g = torch.Generator().manual_seed(3)
     orient = (torch.randint(0, 255, (n, 512, 512), generator=g).to(torch.uint8) * label)
-    image = torch.randint(0, 256, (n, 568, 568, 3), generator=g, dtype=torch.uint8)
+    image = torch.randint(0, 256, (n, 512, 512, 3), generator=g, dtype=torch.uint8)       # stored at 512: bicubic to 568 on the device
     pipe = inputs.DeviceInputPipeline(opt, "cuda", rng=random.Random(7), generator=torch.Generator(device="cuda").manual_seed(1))
     d = pipe(image, label, orient)
     torch.cuda.synchronize()

@@ -146,6 +146,26 @@ def test_crop_flip_to_tensor_matches_pillow(flip):
         assert np.array_equal(got_lab[n], lt.numpy())
 
 
+@pytest.mark.parametrize("hs,ws,hd,wd", [(64, 64, 71, 71), (50, 40, 37, 64), (32, 32, 32, 48), (96, 96, 40, 40)])
+def test_bicubic_restatement_matches_pillow(hs, ws, hd, wd):
+    """transforms.Resize(osize, Image.BICUBIC) is Image.resize (base_dataset.py:421-424): up- and down-scaling, RGB and L."""
+    r = np.random.RandomState(hs + wd)
+    for c in (3, 1):
+        src = r.randint(0, 256, size=(hs, ws, c), dtype=np.uint8)
+        src[:4, :4] = 255
+        src[4:8, :4] = 0                                                         # overshoot on both sides: clip8
+        img = Image.fromarray(src if c == 3 else src[..., 0])
+        want = np.asarray(img.resize((wd, hd), Image.BICUBIC)).reshape(hd, wd, c)
+        assert np.array_equal(IO.pil_bicubic_resize_u8(src, hd, wd), want)
+
+
+def test_bicubic_512_to_568_matches_pillow():
+    """BASELINE configs[4]: load_size 568 from 512x512 stored images."""
+    src = np.random.RandomState(1).randint(0, 256, size=(512, 512, 3), dtype=np.uint8)
+    want = np.asarray(Image.fromarray(src).resize((568, 568), Image.BICUBIC))
+    assert np.array_equal(IO.pil_bicubic_resize_u8(src, 568, 568), want)
+
+
 # ---- cv2 INTER_LINEAR restatement: algorithm properties (cv2 itself is not installed: parity unpinned) --------------
 def test_cv2_resize_linear_properties():
     r = np.random.RandomState(3)
@@ -179,11 +199,18 @@ def test_library_host_helpers_match_oracle():
         assert be.mg_noise_field_len(s) == sum(v * v * 3 for v in IO.noise_octave_sizes(s))
     with pytest.raises(RuntimeError):
         be.mg_nearest_table(0, 4, ctypes.c_void_p(t.data_ptr()))
+    for src, dst in [(512, 568), (96, 40), (40, 64)]:
+        wb, wc = IO.pil_bicubic_table(src, dst)
+        assert be.mg_bicubic_ksize(src, dst) == wc.shape[1]
+        b, c = torch.empty(wb.shape, dtype=torch.int32), torch.empty(wc.shape, dtype=torch.int32)
+        be.mg_bicubic_table(src, dst, ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(c.data_ptr()))
+        assert np.array_equal(b.numpy(), wb) and np.array_equal(c.numpy(), wc)
 
 
 # ---- the pipeline (host glue) on the emulator vs the dataset flow restated with Pillow ---------------------------------------
 @pytest.mark.parametrize("load,stored", [(40, 40), (44, 40)])
 def test_device_input_pipeline_matches_dataset_flow(emulator_backend, load, stored):
+    """Images are stored at `stored` like the maps: Resize(BICUBIC) for them, Resize(NEAREST) for the maps."""
     from michigan_amd.inputs import DeviceInputPipeline
     from michigan_amd.model import default_options
     cs, n = 32, 3
@@ -191,7 +218,7 @@ def test_device_input_pipeline_matches_dataset_flow(emulator_backend, load, stor
     r = np.random.RandomState(5)
     label = np.stack([_ellipse_mask(stored, stored, 20 + i) for i in range(n)])
     orient = (r.randint(0, 255, size=(n, stored, stored)) * label).astype(np.uint8)
-    image = r.randint(0, 256, size=(n, load, load, 3), dtype=np.uint8)
+    image = r.randint(0, 256, size=(n, stored, stored, 3), dtype=np.uint8)
     pipe = DeviceInputPipeline(opt, "cpu", rng=random.Random(42), generator=torch.Generator().manual_seed(1))
     data = pipe(torch.from_numpy(image), torch.from_numpy(label), torch.from_numpy(orient))
 
@@ -205,7 +232,7 @@ def test_device_input_pipeline_matches_dataset_flow(emulator_backend, load, stor
         lab_t[lab_t == 255] = opt.label_nc
         assert torch.equal(data["label_tag"][i], lab_t)
         assert torch.equal(data["orient"][i], tl(orient[i]) * 255)
-        img_t = _pil_transform(image[i], load, (x, y), cs, flip).sub_(0.5).div_(0.5)
+        img_t = _pil_transform(image[i], load, (x, y), cs, flip, nearest=False).sub_(0.5).div_(0.5)
         assert torch.equal(data["image_tag"][i], img_t)
         rgb = IO.trans_orient_to_rgb(orient[i], label[i])
         assert torch.equal(data["orient_rgb"][i], tl(rgb) * lab_t)                # pix2pix_dataset.py:126-127

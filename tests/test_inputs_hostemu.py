@@ -14,7 +14,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INPUT_FNS = ("mg_input_crop_u8", "mg_onehot_labels", "mg_orient_to_rgb_u8", "mg_generate_hole_u8", "mg_noise_octaves",
-             "mg_nearest_table", "mg_orient_rgb_table", "mg_noise_field_len")
+             "mg_nearest_table", "mg_orient_rgb_table", "mg_noise_field_len", "mg_resize_bicubic_u8", "mg_bicubic_ksize", "mg_bicubic_table", "mg_inputs_set_option")
 
 
 @pytest.fixture(scope="module")
@@ -66,6 +66,11 @@ def test_crop_kernel_source(both_on_host, geom, mode):
     both_on_host.test_crop_flip_matches_oracle(geom, mode)
 
 
+@pytest.mark.parametrize("geom", [(2, 64, 64, 71, 71, 3), (1, 50, 40, 37, 64, 1), (2, 96, 96, 40, 40, 3)], ids=str)
+def test_bicubic_kernel_source(both_on_host, geom):
+    both_on_host.test_bicubic_resize_matches_oracle(geom)
+
+
 def test_onehot_kernel_source(both_on_host):
     both_on_host.test_onehot_matches_oracle()
 
@@ -80,9 +85,19 @@ def test_hole_kernel_source(both_on_host, geom):
     both_on_host.test_generate_hole_empty_orientation_mask()
 
 
-@pytest.mark.parametrize("size,n", [(64, 2), (40, 1), (100, 1)])
+@pytest.mark.parametrize("size,n", [(64, 2), (40, 1), (100, 1), (72, 1), (136, 1)])
 def test_noise_kernel_source(both_on_host, size, n):
     both_on_host.test_noise_octaves_match_oracle(size, n)
+
+
+@pytest.mark.parametrize("size,n", [(64, 1), (100, 1), (72, 2)])
+def test_noise_per_pixel_kernel_source(both_on_host, host_kernels, size, n):
+    """The gather form kept behind mg_inputs_set_option(0, 0) (fallback for octaves that do not fit the LDS budget)."""
+    host_kernels.mg_inputs_set_option(0, 0)
+    try:
+        both_on_host.test_noise_octaves_match_oracle(size, n)
+    finally:
+        host_kernels.mg_inputs_set_option(0, 1)
 
 
 def test_noise_kernel_source_is_bit_identical(both_on_host):

@@ -32,7 +32,7 @@ def main():
     yy, xx = torch.meshgrid(torch.arange(512.), torch.arange(512.), indexing="ij")
     label = ((((yy - 256) / 150) ** 2 + ((xx - 256) / 120) ** 2) <= 1).to(torch.uint8).expand(n, 512, 512).contiguous()
     orient = torch.randint(0, 255, (n, 512, 512), generator=g).to(torch.uint8) * label
-    image = torch.randint(0, 256, (n, load, load, 3), generator=g, dtype=torch.uint8)
+    image = torch.randint(0, 256, (n, 512, 512, 3), generator=g, dtype=torch.uint8)        # stored size: bicubic 512 -> 568 on the device
     label, orient, image = label.cuda(), orient.cuda(), image.cuda()
     pipe = inputs.DeviceInputPipeline(opt, "cuda", rng=random.Random(1), generator=torch.Generator(device="cuda").manual_seed(1))
     for _ in range(3):
@@ -53,6 +53,15 @@ def main():
     e.record()
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / a.iters
+    _cabi.backend().mg_inputs_set_option(0, 0)                      # A/B: the per-pixel gather form of the same kernel
+    inputs.noise_from_fields(fields, cs)
+    s.record()
+    for _ in range(a.iters):
+        inputs.noise_from_fields(fields, cs)
+    e.record()
+    torch.cuda.synchronize()
+    ms_gather = s.elapsed_time(e) / a.iters
+    _cabi.backend().mg_inputs_set_option(0, 1)
     alg_bytes = fields.numel() * 8 + n * 3 * cs * cs * 4            # every field value read once, the noise written once
     # CPU: the same per-sample work, reference arithmetic (numpy), one core
     from oracle import inputs_oracle as IO
@@ -67,7 +76,7 @@ def main():
     print(json.dumps({
         "what": "device input pipeline, load 568 -> crop 512, use_ig, batch %d" % n,
         "pipeline_ms_per_batch": round(dt * 1e3, 3), "pipeline_images_per_s": round(n / dt, 1),
-        "noise_kernel_ms": round(ms, 4), "noise_kernel_GBps": round(alg_bytes / ms / 1e6, 1),
+        "noise_kernel_ms": round(ms, 4), "noise_per_pixel_gather_kernel_ms": round(ms_gather, 4), "noise_kernel_GBps": round(alg_bytes / ms / 1e6, 1),
         "noise_kernel_frac_of_8TBps": round(alg_bytes / ms / 1e6 / 8000, 4),
         "noise_algorithmic_MB_per_image": round(alg_bytes / n / 1e6, 2),
         "cpu_port_seconds_per_sample_one_core": round(cpu, 4), "cpu_port_images_per_s_per_core": round(1 / cpu, 2),
