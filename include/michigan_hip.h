@@ -291,7 +291,7 @@ int mg_noise_octaves(const double* fields, float* out, int32_t N, int32_t S, voi
 int mg_resize_bicubic_u8(const uint8_t* src, uint8_t* tmp, uint8_t* dst, const int32_t* xbounds, const int32_t* xcoef, int32_t kx,
                          const int32_t* ybounds, const int32_t* ycoef, int32_t ky, int32_t N, int32_t Hs, int32_t Ws,
                          int32_t Hd, int32_t Wd, int32_t C, void* stream);
-int     mg_inputs_set_option(int32_t key, int32_t value);   /* key 0: 1 = LDS-tiled noise kernel (default), 0 = per-pixel gather form; same results */
+int     mg_inputs_set_option(int32_t key, int32_t value);   /* key 0: 0 = per-pixel noise kernel (default), 1 = LDS-tiled form (A/B); bit-identical results */
 int     mg_bicubic_ksize(int32_t in_size, int32_t out_size);
 int     mg_bicubic_table(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* coef);
 int     mg_nearest_table(int32_t src, int32_t dst, int32_t* table);
@@ -305,7 +305,8 @@ int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* o
 /* Tuning switches for A/B measurements (value 0 / 1, all default 1): key 0 = conv pipeline (0 register-staged
  * double buffer, 1 LDS-DMA ring); 1 = allow 256x256 tiles; 2 = 3x3 halo-tile kernel; 3 = kernel-row 3x3 weight-
  * gradient kernel; 4 = 128-channel x 16x16-pixel halo tiles; 5 = split-K for low-resolution long-K convolutions;
- * 6 = register-weight kernels for 3x3 convolutions over an 8-channel input (forward and weight gradient).
+ * 6 = register-weight kernels for 3x3 convolutions over an 8-channel input (forward and weight gradient);
+ * 7 = bf16 conv epilogues exchange channel quads between the two half-waves (v_permlane32_swap) and store 16 bytes per lane.
  * Results agree within accumulation-order rounding whatever the setting (each setting is bit-reproducible except
  * the weight gradients, which use fp32 atomics). */
 int         mg_set_option(int32_t key, int32_t value);

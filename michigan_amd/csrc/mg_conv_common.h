@@ -27,6 +27,7 @@ struct ConvK {              // kernel-side view of mg_conv_desc (passed by value
     int tiles_y, tiles_x;   // halo kernel: spatial tiles per image
     int ksplit, ntiles;     // generic LDS-DMA kernel: split-K factor (1 = off) and tiles per K slice
     float* ws;              // split-K: fp32 partial sums [ksplit][ngemm][Cout_gemm]
+    int wide;               // bf16 epilogue: lanes l and l+32 exchange quads so that every lane stores 16 contiguous bytes
 };
 namespace {
 
@@ -123,6 +124,22 @@ __device__ __forceinline__ float mg_act_fast(float v, float neg, bool relu)
     return relu ? fmaxf(v, 0.f) : r;
 }
 
+// Wide bf16 stores.  In the MFMA accumulator layout lane l (pixel l & 31, hi = l >> 5) holds channel quads
+// base + rq*8 + hi*4: an 8-byte store per quad makes every store instruction drop 16-byte pieces (lanes l, l+32) at the
+// pixel pitch, and rocprofv3 WRITE_SIZE showed 1.45x (plain) to 2.4x (SPADE, two output arrays) of the algorithmic
+// bytes leaving the L2 for such kernels while fully coalesced kernels write exactly their bytes.  Exchanging quad
+// rq = 2k+1 of the low half-wave with quad 2k of the high half-wave (v_permlane32_swap, gfx950) gives each lane the 8
+// consecutive channels base + k*16 + hi*8: one 16-byte store per lane, 32 contiguous bytes per pixel per instruction.
+// Must be executed by all 64 lanes (no divergent predicate around it).
+__device__ __forceinline__ uint2 mg_pack_bf16x4(f32x4_t v) { uint2 u; u.x = f2bf2(v[0], v[1]); u.y = f2bf2(v[2], v[3]); return u; }
+__device__ __forceinline__ uint4 mg_pair_swap(uint2 even, uint2 odd)
+{
+    const auto a = __builtin_amdgcn_permlane32_swap(even.x, odd.x, false, false);   // a[0]: lo keeps even, hi gets lo's odd; a[1]: lo gets hi's even, hi keeps odd
+    const auto b = __builtin_amdgcn_permlane32_swap(even.y, odd.y, false, false);
+    uint4 r; r.x = a[0]; r.y = b[0]; r.z = a[1]; r.w = b[1];
+    return r;
+}
+
 // Batched epilogue (the common case: channel counts that are multiples of 4, no tanh).  Per-channel parameters
 // come from LDS (conv_stage_params); the only global loads left are the residual / SPADE x quads, issued as a
 // batch before their first use, so a workgroup pays one memory round trip per batch instead of one per
@@ -170,18 +187,34 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
                         mk[rq] = ET<T>::load4(Msk + opix[nt] + (co < d.Cout ? co : 0));
                     }
                 }
+                f32x4_t v[4];
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
-                    const int co = m0 + lr + rq * 8;
-                    f32x4_t v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float t = acc[mt][nt][rq * 4 + j] + bias4[rq][j];
                         if (Res) t += rv[rq][j];
                         t = mg_act_fast(t, neg, relu);
-                        v[j] = (Msk && !(mk[rq][j] > 0.f)) ? 0.f : t;
+                        v[rq][j] = (Msk && !(mk[rq][j] > 0.f)) ? 0.f : t;
                     }
-                    if (pok[nt] && co < d.Cout) ET<T>::store4(Out + opix[nt] + co, v);
+                }
+                bool wide = false;
+                if constexpr (sizeof(T) == 2) wide = d.wide != 0;
+                if (wide) {
+                    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; ++k2) {
+                            const uint4 w = mg_pair_swap(mg_pack_bf16x4(v[2 * k2]), mg_pack_bf16x4(v[2 * k2 + 1]));
+                            const int co = m0 + wm * MT * 32 + mt * 32 + k2 * 16 + hi * 8;
+                            if (pok[nt] && co < d.Cout) *reinterpret_cast<uint4*>(Out + opix[nt] + co) = w;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int co = m0 + lr + rq * 8;
+                        if (pok[nt] && co < d.Cout) ET<T>::store4(Out + opix[nt] + co, v[rq]);
+                    }
                 }
             });
         });
@@ -200,6 +233,45 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) xv[nt][q] = ET<T>::load4(X + opix[nt] + (oc[q] < d.Cout ? oc[q] : 0));
+            bool wide = false;
+            if constexpr (sizeof(T) == 2) wide = d.wide != 0;
+            if (wide) {
+                if constexpr (sizeof(T) == 2) {
+                    f32x4_t bg[2], bb[2], mean4[2], rstd4[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int sub = (h * 2 + q) * 8 + hi * 4;
+                        bg[q] = *reinterpret_cast<const f32x4_t*>(par + lrow + sub);
+                        bb[q] = *reinterpret_cast<const f32x4_t*>(par + lrow + 32 + sub);
+                        mean4[q] = *reinterpret_cast<const f32x4_t*>(par + TM + (lrow >> 1) + sub);
+                        rstd4[q] = *reinterpret_cast<const f32x4_t*>(par + TM + TM / 2 + (lrow >> 1) + sub);
+                    }
+                    const int ocw = ((m0 + lrow) >> 1) + h * 16 + hi * 8;          // this lane's 8 consecutive channels after the exchange
+                    static_for<0, NT>([&](auto nt_) {
+                        constexpr int nt = decltype(nt_)::value;
+                        f32x4_t g[2], hv[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int rq = h * 2 + q;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                g[q][j] = 1.f + acc[0][nt][rq * 4 + j] + bg[q][j];
+                                const float bt = acc[1][nt][rq * 4 + j] + bb[q][j];
+                                const float xh = (xv[nt][q][j] - mean4[q][j]) * rstd4[q][j];
+                                hv[q][j] = mg_act_fast(xh * g[q][j] + bt, neg, relu);
+                            }
+                        }
+                        const uint4 hw = mg_pair_swap(mg_pack_bf16x4(hv[0]), mg_pack_bf16x4(hv[1]));
+                        uint4 gw = hw;
+                        if (G1) gw = mg_pair_swap(mg_pack_bf16x4(g[0]), mg_pack_bf16x4(g[1]));     // G1 is uniform: no divergence around the exchange
+                        if (pok[nt] && ocw < d.Cout) {
+                            const size_t o = opix[nt] + ocw;
+                            *reinterpret_cast<uint4*>(Out + o) = hw;
+                            if (G1) *reinterpret_cast<uint4*>(G1 + o) = gw;
+                        }
+                    });
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int sub = (h * 2 + q) * 8 + hi * 4;

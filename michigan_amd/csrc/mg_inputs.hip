@@ -198,7 +198,8 @@ __global__ void noise_kernel(const double* __restrict__ fields, float* __restric
     }
 }
 
-// Tiled form of the same arithmetic: a workgroup owns a 32 x 8 pixel tile of one sample (128-byte output rows per
+// Tiled form of the same arithmetic (A/B variant, mg_inputs_set_option(0, 1); NOT the default: it measured 12 % slower than
+// the per-pixel kernel -- the gathered taps hit in L1/L2 and were not the limit): a workgroup owns a 32 x 8 pixel tile of one sample (128-byte output rows per
 // channel plane) and first stages, for every octave below full size, the few source texels its pixels interpolate
 // between ((32 >> o) + 3) x ((8 >> o) + 3) at most) into LDS -- the per-pixel kernel above issues 72 gathered 8-byte
 // loads per pixel through the vector L1; here each field value is fetched once per tile and the taps are LDS reads.
@@ -378,7 +379,7 @@ extern "C" int64_t mg_noise_field_len(int32_t S)
     return n;
 }
 
-static int g_noise_tiled = 1;                                  // A/B switch (tools/bench_inputs.py --per-pixel-noise)
+static int g_noise_tiled = 0;                                  // A/B switch: measured on MI355X at 8 x 512^2 the LDS-tiled form takes 86 us, the per-pixel form 77 us
 extern "C" int mg_inputs_set_option(int32_t key, int32_t value)
 {
     MG_CHECK_ARG(key == 0, "mg_inputs_set_option: unknown key");

@@ -148,12 +148,12 @@ def test_noise_tiled_equals_per_pixel_kernel_at_512():
     assert be.name == "hip"
     fields = torch.randn(2, inputs.noise_field_len(512), dtype=torch.float64, device="cuda",
                          generator=torch.Generator(device="cuda").manual_seed(9)) * 0.25 + 0.5
-    tiled = inputs.noise_from_fields(fields, 512)
-    be.mg_inputs_set_option(0, 0)
+    gather = inputs.noise_from_fields(fields, 512)
+    be.mg_inputs_set_option(0, 1)
     try:
-        gather = inputs.noise_from_fields(fields, 512)
+        tiled = inputs.noise_from_fields(fields, 512)
     finally:
-        be.mg_inputs_set_option(0, 1)
+        be.mg_inputs_set_option(0, 0)
     torch.cuda.synchronize()
     assert torch.equal(tiled, gather)
 

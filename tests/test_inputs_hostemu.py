@@ -91,13 +91,13 @@ def test_noise_kernel_source(both_on_host, size, n):
 
 
 @pytest.mark.parametrize("size,n", [(64, 1), (100, 1), (72, 2)])
-def test_noise_per_pixel_kernel_source(both_on_host, host_kernels, size, n):
-    """The gather form kept behind mg_inputs_set_option(0, 0) (fallback for octaves that do not fit the LDS budget)."""
-    host_kernels.mg_inputs_set_option(0, 0)
+def test_noise_tiled_kernel_source(both_on_host, host_kernels, size, n):
+    """The LDS-tiled variant behind mg_inputs_set_option(0, 1)."""
+    host_kernels.mg_inputs_set_option(0, 1)
     try:
         both_on_host.test_noise_octaves_match_oracle(size, n)
     finally:
-        host_kernels.mg_inputs_set_option(0, 1)
+        host_kernels.mg_inputs_set_option(0, 0)
 
 
 def test_noise_kernel_source_is_bit_identical(both_on_host):
