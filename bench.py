@@ -101,7 +101,9 @@ def main():
 
     torch.manual_seed(0)
     opt = default_options(crop_size=a.size, gpu_ids=[local], compute_dtype=a.dtype, inpaint_orient=a.inpaint_orient)
-    trainer = Pix2PixTrainer(opt)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):           # the networks announce themselves like the reference does; stdout carries only the JSON line
+        trainer = Pix2PixTrainer(opt)
     data = {k: v.cuda() for k, v in synth_batch(a.batch_per_gpu, a.size, seed=1234 + rank).items()}
 
     if a.mode == "train":

@@ -27,6 +27,9 @@
 // weight addresses are a wave-uniform base (scalar registers, walked with scalar adds) plus a constant
 // per-lane offset (global_load_lds with an SGPR base), and one s_barrier + one vmcnt wait per tap.
 #include "mg_conv_common.h"
+#ifndef MG_HALO_SCHED
+#define MG_HALO_SCHED 0          // scheduling-hint experiments (tools/ab_halo_sched.sh); 0 = compiler's own schedule
+#endif
 
 extern int g_mg_conv_halo_big;     // mg_set_option(4, v): 0 = never use the 128 x 16x16 geometry
 
@@ -182,6 +185,26 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
                     for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
             }
+#if MG_HALO_SCHED == 1
+            if constexpr (MT == 2 && NT == 4) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+#elif MG_HALO_SCHED == 2
+            if constexpr (MT == 2 && NT == 4) __builtin_amdgcn_iglp_opt(0);
+#elif MG_HALO_SCHED == 3
+            if constexpr (MT == 2 && NT == 4) __builtin_amdgcn_iglp_opt(1);
+#endif
         } else {
             f32x4_t a[MT][2], b[NT][2];
 #pragma unroll
