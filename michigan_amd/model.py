@@ -116,7 +116,17 @@ class Pix2PixModel(nn.Module):
         return d
 
     # -- networks -------------------------------------------------------------------
+    def zeros_padding(self, t):
+        """pix2pix_model.py:495-502: th/2 zeros on every side (the padded canvas the networks see under --add_feat_zeros)."""
+        o = int(self.opt.add_th / 2)
+        r = self.opt.add_th - o
+        return torch.nn.functional.pad(t, (o, r, o, r))
+
     def generate_fake(self, d):
+        if getattr(self.opt, "add_feat_zeros", False):                    # pix2pix_model.py:513-519 (inference.py / the demo)
+            d = dict(d)
+            for k in ("input_ref", "image_ref", "orient", "input_tag", "image_tag", "noise"):
+                d[k] = self.zeros_padding(d[k])
         return self.netG(d["input_ref"], orient_mask=d["orient"], image_ref=d["image_ref"],
                          input_tag=d["input_tag"], noise=d["noise"], image_tag=d["image_tag"])
 

@@ -70,8 +70,41 @@ def make_inpaint():
     print("inpaint golden: out mean %.4f std %.4f" % (out.mean().item(), out.std().item()))
 
 
+INF_CFG = dict(ngf=16, crop_size=64, add_th=64, n=1, seed_w=21, seed_x=23, gain=1.0, expand_th=5)
+
+
+def make_inference():
+    """BASELINE configs[0] (inference.py --add_feat_zeros --expand_mask_be --use_ig): the reference generator in eval
+    mode (running BN statistics, no spectral-norm power iteration, fixed mask dilation) on inputs zero-padded by the
+    reference's own `zeros_padding` (pix2pix_model.py:495-502,513-519); crop 64 + 64 = a 128x128 canvas, 2x2 latent."""
+    R.setup()
+    import types
+    from models.pix2pix_model import Pix2PixModel
+    opt = R.make_opt(ngf=INF_CFG["ngf"], crop_size=INF_CFG["crop_size"], add_feat_zeros=True, add_th=INF_CFG["add_th"],
+                     isTrain=False, expand_mask_be=True, expand_th=INF_CFG["expand_th"], random_expand_mask=False)
+    G = R.build_generator(opt)
+    G.load_state_dict(synth_state_dict(G.state_dict(), seed=INF_CFG["seed_w"], gain=INF_CFG["gain"]))
+    G.eval()
+    b = synth_batch(INF_CFG["n"], INF_CFG["crop_size"], seed=INF_CFG["seed_x"])
+    pad = types.SimpleNamespace(opt=opt)
+    zp = lambda t: Pix2PixModel.zeros_padding(pad, t)
+    with torch.no_grad():
+        out = G(zp(b["input_ref"]), orient_mask=zp(b["orient"]), image_ref=zp(b["image_ref"]), input_tag=zp(b["input_tag"]),
+                noise=zp(b["noise"]), image_tag=zp(b["image_tag"]))
+    o = INF_CFG["add_th"] // 2
+    res = {"out_padded": out.numpy(), "out": out[:, :, o:o + INF_CFG["crop_size"], o:o + INF_CFG["crop_size"]].numpy()}   # inference.py:44-48
+    np.savez_compressed(os.path.join(OUT, "inference_ngf16_c64.npz"), **res)
+    with open(os.path.join(OUT, "inference_config.json"), "w") as fh:
+        json.dump(INF_CFG, fh)
+    print("inference golden: out", out.shape, "mean %.4f std %.4f" % (out.mean().item(), out.std().item()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--inference" in sys.argv:          # only this fixture (the others stay byte-identical)
+        make_inference()
+        return
+    make_inference()
     make_inpaint()
     torch.manual_seed(0)
     opt = R.make_opt(ngf=CFG["ngf"], ndf=CFG["ndf"], crop_size=CFG["crop_size"], random_expand_mask=True,

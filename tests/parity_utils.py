@@ -151,3 +151,23 @@ def compare(res, gold, *, atol_out, rtol_stat, rtol_grad, keys=None):
         if not np.isfinite(err) or err > lim:
             bad.append("%s: err %.3e > %.1e" % (k, err, lim))
     assert not bad, "golden mismatch:\n  " + "\n  ".join(bad)
+
+
+def run_inference_config0(device, dtype=torch.float32):
+    """BASELINE configs[0] at the fixture size: Pix2PixModel(mode='inference') with --add_feat_zeros --expand_mask_be, eval
+    mode, the reference's own weights (seeded) -- what oracle/make_golden.py:make_inference ran through the reference."""
+    from michigan_amd.model import Pix2PixModel, default_options
+    from michigan_amd.synth import synth_batch, synth_state_dict
+    with open(os.path.join(GOLDEN, "inference_config.json")) as fh:
+        cfg = json.load(fh)
+    opt = default_options(ngf=cfg["ngf"], crop_size=cfg["crop_size"], add_feat_zeros=True, add_th=cfg["add_th"], isTrain=False,
+                          expand_mask_be=True, expand_th=cfg["expand_th"], random_expand_mask=False, gpu_ids=[],
+                          compute_dtype="fp32" if dtype == torch.float32 else "bf16")
+    model = Pix2PixModel(opt)
+    model.netG.load_state_dict(synth_state_dict(model.netG.state_dict(), seed=cfg["seed_w"], gain=cfg["gain"]))
+    model.to(device).eval()
+    model.netG.set_compute_dtype(dtype)
+    data = {k: v.to(device) for k, v in synth_batch(cfg["n"], cfg["crop_size"], seed=cfg["seed_x"]).items()}
+    out = model(data, mode="inference")
+    o, cs = cfg["add_th"] // 2, cfg["crop_size"]
+    return {"out_padded": out.float().cpu().numpy(), "out": out[:, :, o:o + cs, o:o + cs].float().cpu().numpy()}   # inference.py:44-48

@@ -164,3 +164,13 @@ def test_train_step_runs_and_updates(hip_backend):
     assert all(torch.isfinite(v).all() for v in tr.d_losses.values()), tr.d_losses
     assert not torch.equal(d0, tr.optimizer_D.flat)
     assert set(tr.get_latest_losses()) == {"GAN", "GAN_Feat", "VGG", "ORIENT", "D_Fake", "D_real"}
+
+
+def test_inference_config0_fp32_matches_reference_golden(hip_backend):
+    """BASELINE configs[0] on the HIP kernels: Pix2PixModel(mode='inference'), eval-mode BN / spectral norm, zero-padded
+    canvas (--add_feat_zeros), against the image the reference produced; fp32 tolerance = the north star's L_inf < 1e-3."""
+    import numpy as np
+    res, gold = PU.run_inference_config0("cuda"), PU.golden("inference_ngf16_c64.npz")
+    err = np.abs(res["out_padded"] - gold["out_padded"]).max()
+    assert err < 1e-3, f"inference L_inf vs reference {err:.3e}"
+    assert np.abs(res["out"] - gold["out"]).max() < 1e-3

@@ -59,3 +59,12 @@ def test_generator_matches_reference_golden(emulator_backend):
 def test_discriminator_vgg_losses_match_reference_golden(emulator_backend):
     res = PU.run_discriminator_vgg("cpu")
     PU.compare(res, PU.golden("discriminator_vgg_ngf16_c128.npz"), atol_out=5e-5, rtol_stat=1e-4, rtol_grad=2e-3)
+
+
+def test_inference_config0_matches_reference_golden(emulator_backend):
+    """BASELINE configs[0] (inference.py: eval mode, --add_feat_zeros zero-padded canvas, fixed mask dilation)."""
+    import numpy as np
+    res, gold = PU.run_inference_config0("cpu"), PU.golden("inference_ngf16_c64.npz")
+    assert res["out_padded"].shape == gold["out_padded"].shape
+    assert np.abs(res["out_padded"] - gold["out_padded"]).max() < 5e-5
+    assert np.abs(res["out"] - gold["out"]).max() < 5e-5
