@@ -35,6 +35,7 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = C.MG_ACT_NONE, C.MG_ACT_RELU, C.MG_ACT
 WGRAD_USE_TR = True
 # Process group used to synchronise batch-norm statistics (set by michigan_amd.parallel); None = local stats.
 SYNC_BN_GROUP = None
+STATS_FROM_UPSAMPLE_SOURCE = True     # batch statistics of a 2x-upsampled tensor from its quarter-size source (A/B: tools/ab_pyflag.py)
 
 
 def _dt(t: torch.Tensor) -> int:
@@ -408,7 +409,13 @@ def batch_stats_begin(x: torch.Tensor):
         x = _nhwc(x)
         c = x.shape[-1]
         count = x.numel() // c
-        sums = channel_sums(x)
+        src = getattr(x, "_mg_stats_src", None) if STATS_FROM_UPSAMPLE_SOURCE else None
+        if src is not None and src.shape[-1] == c and 4 * src.numel() == x.numel():
+            # x = nearest 2x upsample of src (upsample2x): every source value occurs exactly four times, so
+            # sum(x) = 4 sum(src) and sum(x^2) = 4 sum(src^2) -- reduce the quarter-size tensor (x4 is exact in fp32)
+            sums = channel_sums(src).mul_(4.0)
+        else:
+            sums = channel_sums(x)
         work = None
         if SYNC_BN_GROUP is not None:
             import torch.distributed as dist
@@ -721,8 +728,11 @@ def reflect_pad(x: torch.Tensor, p: int) -> torch.Tensor:
 
 
 def upsample2x(x):
-    """nn.Upsample(scale_factor=2, mode='nearest') on NHWC."""
-    return _Up2Fn.apply(x)
+    """nn.Upsample(scale_factor=2, mode='nearest') on NHWC.  The result remembers its source so that batch
+    statistics of it (SPADE norm_0 / norm_s of the next block) can be reduced from the quarter-size tensor."""
+    y = _Up2Fn.apply(x)
+    y._mg_stats_src = x.detach()
+    return y
 
 
 def avgpool3s2(x):
