@@ -247,8 +247,10 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int,
 def _wgrad_launch(x, dy, taps, stride, want_bias):
     n, h, w, cin = x.shape
     _, hj, wj, cg8 = dy.shape
-    dw = torch.zeros((len(taps), cg8, cin), dtype=torch.float32, device=x.device)
-    dbias = torch.zeros(cg8, dtype=torch.float32, device=x.device) if want_bias else None
+    ndw = len(taps) * cg8 * cin
+    buf = torch.zeros(ndw + (cg8 if want_bias else 0), dtype=torch.float32, device=x.device)    # one fill for both atomic targets
+    dw = buf[:ndw].view(len(taps), cg8, cin)
+    dbias = buf[ndw:] if want_bias else None
     d = C.WgradDesc()
     d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
     d.dbias = dbias.data_ptr() if want_bias else None
