@@ -583,3 +583,42 @@ def test_gabor_argmax_and_orientation_loss(dt):
     tol = 1e-4 if dt == "f32" else 2e-2
     assert abs(float(want_o) - float(got_o)) < tol * max(1.0, abs(float(want_o)))
     assert abs(float(want_c) - float(got_c)) < tol * max(1.0, abs(float(want_c)))
+
+
+@pytest.mark.parametrize("epi", ["plain", "plain+resid", "spade"])
+def test_wide_epilogue_stores_are_bit_identical_to_quad_stores(epi):
+    """mg_set_option(7, v): the half-wave quad exchange (v_permlane32_swap) + 16-byte stores against the 8-byte-per-quad
+    stores it replaces, bf16, on a halo-kernel shape and a generic-kernel shape -- same bits (only the store width changes)."""
+    from michigan_amd import _cabi, ops
+    be = _cabi.backend()
+    g = torch.Generator().manual_seed(31)
+    outs = []
+    for v in (1, 0):
+        be.mg_set_option(7, v)
+        try:
+            res = []
+            for (n, h, w, cin, cout, k, s, p) in [(2, 48, 64, 64, 128, 3, 1, 1), (2, 33, 29, 64, 72, 4, 2, 1)]:
+                gg = torch.Generator().manual_seed(n * h + cout)
+                x = torch.randn(n, h, w, cin, generator=gg).bfloat16().cuda()
+                wt = (torch.randn(cout, cin, k, k, generator=gg) / (cin * k * k) ** 0.5).cuda()
+                b = torch.randn(cout, generator=gg).cuda()
+                if epi == "spade" and k == 3:
+                    c = cout // 2
+                    xin = torch.randn(n, h, w, c, generator=gg).bfloat16().cuda()
+                    mean, rstd = torch.randn(c, generator=gg).cuda(), (torch.rand(c, generator=gg) + 0.5).cuda()
+                    wb = (torch.randn(c, cin, 3, 3, generator=gg) / 24).cuda()
+                    y = ops.spade_modulate(xin, x, wt[:c].contiguous(), b[:c].contiguous(), wb, b[c:2 * c].contiguous(), mean, rstd,
+                                           float(n * h * w), act=ops.ACT_LRELU)
+                elif epi == "spade":
+                    continue
+                else:
+                    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+                    r = torch.randn(n, ho, wo, cout, generator=gg).bfloat16().cuda() if epi == "plain+resid" else None
+                    y = ops.conv2d(x, wt, b, stride=s, padding=p, act=ops.ACT_LRELU, resid=r)
+                res.append(y.detach().clone())
+            torch.cuda.synchronize()
+            outs.append(res)
+        finally:
+            be.mg_set_option(7, 1)
+    for a, b_ in zip(*outs):
+        assert torch.equal(a.view(torch.int16), b_.view(torch.int16))
