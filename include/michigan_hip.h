@@ -306,7 +306,8 @@ int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* o
  * double buffer, 1 LDS-DMA ring); 1 = allow 256x256 tiles; 2 = 3x3 halo-tile kernel; 3 = kernel-row 3x3 weight-
  * gradient kernel; 4 = 128-channel x 16x16-pixel halo tiles; 5 = split-K for low-resolution long-K convolutions;
  * 6 = register-weight kernels for 3x3 convolutions over an 8-channel input (forward and weight gradient);
- * 7 = bf16 conv epilogues exchange channel quads between the two half-waves (v_permlane32_swap) and store 16 bytes per lane.
+ * 7 = bf16 conv epilogues exchange channel quads between the two half-waves (v_permlane32_swap) and store 16 bytes per lane;
+ * 8 = wave-per-pixel dot-product kernel for convolutions with <= 4 output channels over >= 128 input channels (the discriminators' heads).
  * Results agree within accumulation-order rounding whatever the setting (each setting is bit-reproducible except
  * the weight gradients, which use fp32 atomics). */
 int         mg_set_option(int32_t key, int32_t value);

@@ -21,6 +21,7 @@ int g_mg_conv_halo = 1;          // 3x3 stride-1 convs on the LDS halo-tile kern
 int g_mg_conv_bigtiles = 1;      // allow the 128x256 / 256x256 tiles (mg_set_option(1, v))
 extern int g_mg_wgrad3x3;          // mg_wgrad.hip (mg_set_option(3, v))
 extern int g_mg_conv_thin;         // mg_conv_thin.hip (mg_set_option(6, v))
+extern int g_mg_conv_dot;          // mg_conv_dot.hip (mg_set_option(8, v))
 int g_mg_conv_wide = 1;          // bf16 epilogues store 16 bytes per lane after a half-wave quad exchange (mg_set_option(7, v))
 int g_mg_conv_pipeline = 1;      // 0 = register-staged double buffer, 1 = LDS-DMA 3-stage ring (mg_set_option(0, v))
 
@@ -516,6 +517,7 @@ template <typename T>
 int dispatch_conv(ConvK& k, int epilogue, hipStream_t st)
 {
     if (conv_thin_applies(k, ET<T>::DT, epilogue)) return launch_conv_thin(k, st);
+    if (conv_dot_applies(k, ET<T>::DT, epilogue)) return launch_conv_dot(k, ET<T>::DT, st);
     if (halo_applies<T>(k)) return launch_conv_halo(k, ET<T>::DT, epilogue, st);
     return epilogue == MG_EPI_SPADE ? dispatch_tiles<T, MG_EPI_SPADE>(k, st) : dispatch_tiles<T, MG_EPI_PLAIN>(k, st);
 }
@@ -570,5 +572,6 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 5 && (value == 0 || value == 1)) { g_mg_conv_splitk = value; return MG_OK; }
     if (key == 6 && (value == 0 || value == 1)) { g_mg_conv_thin = value; return MG_OK; }
     if (key == 7 && (value == 0 || value == 1)) { g_mg_conv_wide = value; return MG_OK; }
+    if (key == 8 && (value == 0 || value == 1)) { g_mg_conv_dot = value; return MG_OK; }
     return mg_fail(MG_ERR_ARG, "mg_set_option: unknown key/value %d/%d", key, value);
 }
