@@ -106,6 +106,13 @@ class HipBackend:
     name = "hip"
 
     def __init__(self, path: str = LIB_PATH):
+        if not os.path.exists(path) and path == LIB_PATH and os.environ.get("MG_AUTOBUILD", "1") != "0":
+            # a source-only checkout (the .so is git-ignored): compile the HIP library in-tree once -- still the native
+            # path, never a fallback; without hipcc this raises like the missing library would
+            import sys
+            print("[michigan_amd] libmichigan_hip.so missing: building it with hipcc (gfx950), ~2 min", file=sys.stderr, flush=True)
+            from . import build as _build
+            _build.build(verbose=False)
         if not os.path.exists(path):
             raise RuntimeError(
                 f"libmichigan_hip.so not found at {path}: build it with "
