@@ -1,0 +1,139 @@
+"""Reference-side binding: make the UNMODIFIED reference (tzt101/MichiGAN) run its generator, discriminator, VGG tower
+and hot-path losses on the HIP kernels of this package.
+
+    import michigan_amd.dropin as dropin
+    dropin.install()                 # before `TrainOptions().parse()` / `Pix2PixTrainer(opt)` / `Pix2PixModel(opt)`
+
+What the reference's plug-in mechanism needs (models/networks/__init__.py:16-48, util/util.py:180-192):
+  * `find_network_using_name(opt.netG, 'generator')` walks `models.networks.generator.__dict__` for a class whose
+    lower-cased name is `spadebgenerator` and asserts `issubclass(cls, models.networks.base_network.BaseNetwork)`;
+  * losses are attributes of the package (`networks.GANLoss`, `networks.VGGLoss`, ... models/pix2pix_model.py:36-56);
+    `VGGLoss` / `StyleContentLoss` find the tower as `models.networks.loss.VGG19` (loss.py:9,181,659);
+  * the trainer imports `DataParallelWithCallback` from `models.networks.sync_batchnorm` (trainers/pix2pix_trainer.py:6).
+install() therefore patches exactly those names, in the reference's own modules, with subclasses of the HIP classes
+that ALSO inherit the reference's `BaseNetwork` (so the `issubclass` assertion holds), and leaves every other name of
+the reference package (StyleContentLoss, LabColorLoss, ConvEncoder, the other generators, ...) in place.
+
+Only the three top-level networks (+ the frozen in-painting net) and the loss classes are swapped: they take and
+return the reference's NCHW tensors.  The inner modules of this package (SPADE, SPADEResnetBlock, ...) exchange NHWC
+activations and are deliberately NOT patched into `models.networks.architecture / normalization`, where the
+reference's other generators still use the NCHW originals.
+"""
+from __future__ import annotations
+
+import importlib
+import sys
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import networks as hip
+
+_DTYPES = {"fp32": torch.float32, "f32": torch.float32, "bf16": torch.bfloat16, None: None,
+           torch.float32: torch.float32, torch.bfloat16: torch.bfloat16}
+_SAVED: Dict[Tuple[str, str], object] = {}
+_INSTALLED = False
+
+
+def _net_class(hip_cls, ref_base, dtype, ref_module):
+    """A class named like the reference's, behaving like `hip_cls`, passing `issubclass(., ref BaseNetwork)`."""
+    ns = {"__module__": ref_module, "__doc__": hip_cls.__doc__, "_mg_dropin": True}
+    if dtype is not None:
+        ns["compute_dtype"] = dtype
+    bases = (hip_cls,) if issubclass(hip_cls, ref_base) else (hip_cls, ref_base)
+    return type(hip_cls.__name__, bases, ns)
+
+
+def _set(modname: str, attr: str, value):
+    mod = importlib.import_module(modname)
+    key = (modname, attr)
+    if key not in _SAVED:
+        _SAVED[key] = getattr(mod, attr, _MISSING)
+    setattr(mod, attr, value)
+
+
+_MISSING = object()
+
+
+def install(compute_dtype: Optional[str] = "fp32", losses: bool = True, data_parallel: bool = True) -> Dict[str, type]:
+    """Patch the HIP classes into the reference's `models.networks` package (which must be importable: the
+    reference's root on sys.path).  `compute_dtype`: activation dtype of the patched networks ("fp32" | "bf16").
+    `losses=False` keeps the reference's loss classes (they then consume the HIP networks' NCHW outputs with ATen ops).
+    `data_parallel=False` keeps the reference's nn.DataParallel wrapper.  Returns {name: patched class}.  Idempotent."""
+    global _INSTALLED
+    dtype = _DTYPES[compute_dtype]
+    try:
+        ref_base = importlib.import_module("models.networks.base_network").BaseNetwork
+        importlib.import_module("models.networks")
+    except ImportError as e:                       # pragma: no cover - message matters, not the path
+        raise ImportError("michigan_amd.dropin.install(): the reference package `models.networks` is not importable "
+                          "(put the MichiGAN checkout on sys.path first): %s" % e)
+    if getattr(sys.modules["models.networks"], "__name__", "") == hip.__name__:
+        raise RuntimeError("models.networks is already aliased to michigan_amd.networks; install() patches the reference's own package")
+
+    G = _net_class(hip.SPADEBGenerator, ref_base, dtype, "models.networks.generator")
+    IG = _net_class(hip.InpaintGenerator, ref_base, dtype, "models.networks.generator")
+    D = _net_class(hip.MultiscaleDiscriminator, ref_base, dtype, "models.networks.discriminator")
+    ND = _net_class(hip.NLayerDiscriminator, ref_base, dtype, "models.networks.discriminator")
+
+    class _D(D):                                   # the multiscale net builds its PatchGANs through this hook (discriminator.py:37-44)
+        def create_single_discriminator(self, opt):
+            if opt.netD_subarch != "n_layer":
+                raise ValueError("unrecognized discriminator subarchitecture %s" % opt.netD_subarch)
+            return ND(opt)
+    _D.__name__ = _D.__qualname__ = "MultiscaleDiscriminator"
+    _D.__module__ = "models.networks.discriminator"
+    D = _D
+
+    vgg_ns = {"__module__": "models.networks.architecture", "_mg_dropin": True}
+    if dtype is not None:
+        vgg_ns["compute_dtype"] = dtype
+    V = type("VGG19", (hip.VGG19,), vgg_ns)
+    patched = {"SPADEBGenerator": G, "InpaintGenerator": IG, "MultiscaleDiscriminator": D, "NLayerDiscriminator": ND, "VGG19": V}
+
+    for name in ("SPADEBGenerator", "InpaintGenerator"):
+        _set("models.networks.generator", name, patched[name])
+        _set("models.networks", name, patched[name])                  # `from models.networks.generator import *` copies
+    for name in ("MultiscaleDiscriminator", "NLayerDiscriminator"):
+        _set("models.networks.discriminator", name, patched[name])
+        _set("models.networks", name, patched[name])
+    _set("models.networks.architecture", "VGG19", V)
+    _set("models.networks.loss", "VGG19", V)                          # VGGLoss / StyleContentLoss look it up here
+    _set("models.networks", "VGG19", V)
+
+    if losses:
+        class VGGLoss(hip.VGGLoss):
+            def __init__(self, opt=None, vgg=None):
+                super().__init__(opt, vgg if vgg is not None else V())
+        VGGLoss.__module__ = "models.networks.loss"
+        for name, cls in (("GANLoss", hip.GANLoss), ("GANFeatLoss", hip.GANFeatLoss), ("VGGLoss", VGGLoss), ("L1OLoss", hip.L1OLoss)):
+            _set("models.networks.loss", name, cls)
+            _set("models.networks", name, cls)
+            patched[name] = cls
+    if data_parallel:
+        _set("models.networks.sync_batchnorm", "DataParallelWithCallback", hip.DataParallelWithCallback)
+        if "trainers.pix2pix_trainer" in sys.modules:                   # bound by `from ... import` at its import time
+            _set("trainers.pix2pix_trainer", "DataParallelWithCallback", hip.DataParallelWithCallback)
+        patched["DataParallelWithCallback"] = hip.DataParallelWithCallback
+    _INSTALLED = True
+    return patched
+
+
+def uninstall() -> None:
+    """Put the reference's own classes back."""
+    global _INSTALLED
+    for (modname, attr), old in _SAVED.items():
+        mod = sys.modules.get(modname)
+        if mod is None:
+            continue
+        if old is _MISSING:
+            if hasattr(mod, attr):
+                delattr(mod, attr)
+        else:
+            setattr(mod, attr, old)
+    _SAVED.clear()
+    _INSTALLED = False
+
+
+def installed() -> bool:
+    return _INSTALLED

@@ -83,7 +83,27 @@ class Pix2PixModel(nn.Module):
             if dst not in out:
                 nc = self.opt.label_nc + (1 if self.opt.contain_dontcare_label else 0)
                 out[dst] = inputs.onehot_labels(data[src].to(dev), nc)        # zeros().scatter_(1, label.long(), 1.0)
+        self._check_orientation(out)
         return out
+
+    def _check_orientation(self, d):
+        """Under --use_ig the networks consume the 2-channel (sin 2t, cos 2t) x mask map the in-painting net produces
+        (pix2pix_model.py:260-263,407-429); without it, the loader's 1-channel 0..255 map (converted inside G / D / the
+        orientation loss).  Anything else would be zero-padded into the wrong weight channels by the kernels' channel
+        padding, so it is refused here."""
+        o = d.get("orient")
+        if o is None or self.opt.no_orientation:
+            return
+        if self.opt.use_ig:
+            if self.netIG is not None:
+                missing = [k for k in ("hole", "orient_rgb", "noise") if k not in d]
+                if missing:
+                    raise ValueError("use_ig + inpaint_orient: the in-painting net needs %s" % missing)
+            elif o.shape[1] != self.opt.orient_nc:
+                raise ValueError(f"use_ig: orient has {o.shape[1]} channel(s), expected the in-painted {self.opt.orient_nc}-channel "
+                                 "map (enable opt.inpaint_orient to run the frozen in-painting net on hole / orient_rgb / noise)")
+        elif o.shape[1] != 1:
+            raise ValueError(f"orient has {o.shape[1]} channels; without use_ig the loader's 1-channel 0..255 map is expected")
 
     def orientation_planes(self, d):
         o = d["orient"]

@@ -20,9 +20,8 @@ Reference call sites replaced (all ATen today):
 from __future__ import annotations
 
 import ctypes
-from typing import List, Optional, Sequence, Tuple
-
 import weakref
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -126,23 +125,38 @@ def pack_weight(w0: torch.Tensor, w1: Optional[torch.Tensor], dtype, rows_p: int
     """Reference-layout fp32 weight(s) [Cout, Cin, kh, kw] -> GEMM image [taps, rows_p, cols_p] in `dtype`
     (one HIP launch: permute + zero-pad + cast; two tensors = fused SPADE gamma/beta row interleave).
     mode 0: rows = output channels (forward / wgrad image); mode 1: rows = input channels (dgrad image).
-    Images of frozen leaf weights (the VGG tower: requires_grad False, no autograd history) are cached per tensor
-    version, so the tower's weights are packed once instead of on each of its three passes per step."""
-    key = None
-    if w1 is None and not w0.requires_grad and w0.grad_fn is None and w0.is_leaf:
-        key = (w0.data_ptr(), w0._version, dtype, rows_p, cols_p, mode, tuple(w0.shape))
-        hit = _PACK_CACHE.get(key)
-        if hit is not None and hit[0]() is w0:
-            return hit[1]
+
+    Packed images of registered nn.Parameters are cached until the weights change: the key carries the tensors'
+    autograd version counters (bumped by every in-place torch op: init, load_state_dict, torch.optim) AND the global
+    update count of the flat arena they live in, which FlatAdam.step advances because its raw-pointer HIP kernel
+    updates the arena without touching the version counters.  So the discriminator (run in the G step and again, unchanged, in the D step), the VGG tower
+    (three passes per step) and the in-painting net are packed once per weight state instead of once per launch.
+    Tensors that are not parameters (per-forward spectral-norm products W / sigma) are never cached."""
+    slot = None
+    if isinstance(w0, torch.nn.Parameter) and (w1 is None or isinstance(w1, torch.nn.Parameter)):
+        slot = (w0.data_ptr(), 0 if w1 is None else w1.data_ptr(), dtype, rows_p, cols_p, mode)
+        state = (w0._version, 0 if w1 is None else w1._version, _arena_epoch(w0), 0 if w1 is None else _arena_epoch(w1))
+        hit = _PACK_CACHE.get(slot)
+        # identity through weak references: a freed parameter's address (and version 0) can be re-used by a new one
+        if hit is not None and hit[0] == state and hit[1]() is w0 and (w1 is None or hit[2]() is w1):
+            return hit[3]
     dst = _pack_weight(w0, w1, dtype, rows_p, cols_p, mode)
-    if key is not None:
-        if len(_PACK_CACHE) > 256:
-            _PACK_CACHE.clear()
-        _PACK_CACHE[key] = (weakref.ref(w0), dst)
+    if slot is not None:
+        if len(_PACK_CACHE) > 4096:                                  # slots of parameters that no longer exist
+            for k in [k for k, v in _PACK_CACHE.items() if v[1]() is None]:
+                del _PACK_CACHE[k]
+        _PACK_CACHE[slot] = (state, weakref.ref(w0), None if w1 is None else weakref.ref(w1), dst)   # one image per slot: a stale one is replaced
     return dst
 
 
 _PACK_CACHE = {}
+
+
+def _arena_epoch(p) -> int:
+    """Update count of the flat optimiser arena a parameter lives in (optim.FlatAdam tags its parameters with
+    `_mg_arena`); 0 for parameters torch updates itself (their version counter moves instead)."""
+    arena = getattr(p, "_mg_arena", None)
+    return 0 if arena is None else arena.weight_epoch
 
 
 def _pack_weight(w0, w1, dtype, rows_p, cols_p, mode):
@@ -374,7 +388,7 @@ def conv2d_infer(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
         raise ValueError(f"conv2d_infer: input has {cx} channels < weight Cin {cin}")
     ho = (h + 2 * padding - dilation * (kh - 1) - 1) // stride + 1
     wo = (w + 2 * padding - dilation * (kw - 1) - 1) // stride + 1
-    wp = pack_weight(weight.detach(), None, x.dtype, _roundup(cout, 128), cx, 0)
+    wp = pack_weight(weight, None, x.dtype, _roundup(cout, 128), cx, 0)
     bp = bias.detach().float().contiguous() if bias is not None else None
     out = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
     _launch_conv(x, wp, out, bp, fwd_taps(kh, kw, padding, dilation), Hj=ho, Wj=wo, isy=stride, isx=stride,
@@ -393,7 +407,7 @@ def conv_transpose2d_infer(x: torch.Tensor, weight: torch.Tensor, bias: Optional
     if cx < cin or cout % 8:
         raise ValueError("conv_transpose2d_infer: input channels must cover Cin and Cout must be a multiple of 8")
     ho, wo = (h - 1) * stride - 2 * padding + kh, (w - 1) * stride - 2 * padding + kw
-    wt = pack_weight(weight.detach(), None, x.dtype, _roundup(cout, 128), cx, 1)    # columns past Cin are zero
+    wt = pack_weight(weight, None, x.dtype, _roundup(cout, 128), cx, 1)    # columns past Cin are zero
     y = conv_dgrad(x, wt, kh, kw, stride, padding, (ho, wo), cout)
     if bias is not None:
         y = y + bias.detach().to(y.dtype)

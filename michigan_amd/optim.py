@@ -25,6 +25,7 @@ class FlatAdam:
         self.lr, self.betas, self.eps = lr, (float(betas[0]), float(betas[1])), eps
         self.param_groups = [{"lr": lr, "params": self.params}]        # lr schedulers poke this like torch optimisers
         self.step_count = 0
+        self.weight_epoch = 0            # advanced by every step(): part of ops.pack_weight's cache key
         self.group = group
         self.world = dist.get_world_size(group) if (group is not None) else 1
         self.dp = group is not None                  # world == 1 only under the MG_DP_FORCE test hook
@@ -64,6 +65,7 @@ class FlatAdam:
             self.flat[off:off + n].copy_(p.data.reshape(-1).float())
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.flat_grad[off:off + n].view(p.shape)
+            p._mg_arena = self
             self._spans.append((off, off + n))
             off += n
 
@@ -73,6 +75,7 @@ class FlatAdam:
         self._build_arena()
         self.exp_avg.copy_(m.to(self.exp_avg.device))
         self.exp_avg_sq.copy_(v.to(self.exp_avg.device))
+        self.weight_epoch += 1
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_grad.zero_()
@@ -126,3 +129,4 @@ class FlatAdam:
         lr = self.param_groups[0]["lr"]
         ops.adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, lr=lr, beta1=self.betas[0],
                       beta2=self.betas[1], eps=self.eps, step=self.step_count, grad_scale=1.0 / self.world)
+        self.weight_epoch += 1           # the kernel wrote the arena through raw pointers: cached packed weights (ops.pack_weight) are stale

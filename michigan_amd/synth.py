@@ -48,6 +48,19 @@ def synth_batch(n: int, size: int, seed: int = 1234) -> Dict[str, torch.Tensor]:
     return out
 
 
+def synth_loader_batch(n: int, size: int, seed: int = 1234) -> Dict[str, object]:
+    """The `data` dict one iteration of the reference's DataLoader yields (data/pix2pix_dataset.py:178-188), i.e. the
+    argument of `Pix2PixTrainer.run_generator_one_step`: label index maps [n,1,s,s] (ref == tag), images, the 1-channel
+    0..255 orientation map, hole, RGB-coded orientation, noise, instance placeholder and paths.  Same draws as
+    synth_batch (the shared tensors are bit-identical)."""
+    b = synth_batch(n, size, seed)
+    g3 = torch.Generator().manual_seed(seed + 104729)
+    orient255 = torch.floor(torch.rand(n, 1, size, size, generator=g3) * 255.0) * b["hair"]
+    return {"label_ref": b["hair"].clone(), "label_tag": b["hair"].clone(), "instance": torch.zeros(n),
+            "image_ref": b["image_ref"], "image_tag": b["image_tag"], "orient": orient255, "hole": b["hole"],
+            "orient_rgb": b["orient_rgb"], "noise": b["noise"], "path": ["synthetic_%d" % i for i in range(n)]}
+
+
 def synth_state_dict(template: Dict[str, torch.Tensor], seed: int = 0, gain: float = 1.0) -> Dict[str, torch.Tensor]:
     """Fill a state_dict (keys/shapes from `template`) with values that depend only on (key, shape, seed).
 

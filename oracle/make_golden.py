@@ -99,8 +99,35 @@ def make_inference():
     print("inference golden: out", out.shape, "mean %.4f std %.4f" % (out.mean().item(), out.std().item()))
 
 
+def make_trainer(tags=("A", "B")):
+    """The reference's own Pix2PixTrainer (trainers/pix2pix_trainer.py + models/pix2pix_model.py, option namespace from
+    its own parser on the README flags) driven by oracle/trainer_parity.drive: every loss of each iteration, the generated
+    image, a few updated weights, running statistics and spectral-norm vectors after the last iteration."""
+    import tempfile
+    from oracle import trainer_parity as TP
+    R.setup()
+    from trainers.pix2pix_trainer import Pix2PixTrainer
+    for tag in tags:
+        cfg = TP.CFGS[tag]
+        with tempfile.TemporaryDirectory() as ck:
+            opt = R.reference_options(TP.reference_argv(cfg, ck), train=True)
+            if cfg["use_ig"]:
+                R.write_inpaint_checkpoint(opt, seed=cfg["seed_ig"], gain=cfg["gain"])
+            torch.manual_seed(0)
+            trainer = Pix2PixTrainer(opt)
+            TP.load_weights(trainer, cfg)
+            rec = TP.drive(trainer, cfg)
+        np.savez_compressed(os.path.join(OUT, "trainer_%s.npz" % tag), **rec)
+        print("trainer golden", tag, {k: float(v) for k, v in rec.items() if ".loss." in k})
+    with open(os.path.join(OUT, "trainer_config.json"), "w") as fh:
+        json.dump(TP.CFGS, fh)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--trainer" in sys.argv:            # only these fixtures
+        make_trainer()
+        return
     if "--inference" in sys.argv:          # only this fixture (the others stay byte-identical)
         make_inference()
         return

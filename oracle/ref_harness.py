@@ -79,7 +79,23 @@ def setup():
         torch.cuda.FloatTensor = torch.FloatTensor
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
+    _adam_float_betas()
     _ready = True
+
+
+def _adam_float_betas():
+    """models/pix2pix_model.py:141 passes `beta1 = 0` (an int); torch >= 2.x rejects mixed int/float betas.  Cast from
+    the outside (SURVEY.md section 8c shim 1) -- the arithmetic is unchanged."""
+    if getattr(torch.optim.Adam, "_mg_float_betas", False):
+        return
+    orig = torch.optim.Adam.__init__
+
+    def init(self, params, lr=1e-3, betas=(0.9, 0.999), *a, **k):
+        if not isinstance(betas[0], torch.Tensor):
+            betas = (float(betas[0]), float(betas[1]))
+        orig(self, params, lr, betas, *a, **k)
+    torch.optim.Adam.__init__ = init
+    torch.optim.Adam._mg_float_betas = True
 
 
 def make_opt(**over) -> argparse.Namespace:
@@ -131,3 +147,44 @@ def losses():
     setup()
     import models.networks.loss as L
     return L
+
+
+def reference_options(argv, train: bool = True):
+    """Run the reference's OWN option parser (options/{base,train,test}_options.py) on `argv` and apply the
+    post-processing of BaseOptions.parse (base_options.py:205-240) except its side effects (printing, writing
+    checkpoints/<name>/opt.txt, torch.cuda.set_device).  If michigan_amd.dropin is installed, the generator's /
+    discriminator's `modify_commandline_options` hooks that run here are the HIP classes' hooks."""
+    setup()
+    old = sys.argv
+    sys.argv = ["train.py" if train else "inference.py"] + list(argv)
+    try:
+        if train:
+            from options.train_options import TrainOptions as Opt
+        else:
+            from options.test_options import TestOptions as Opt
+        o = Opt()
+        opt = o.gather_options()
+        opt.isTrain = o.isTrain
+    finally:
+        sys.argv = old
+    opt.semantic_nc = opt.label_nc + (1 if opt.contain_dontcare_label else 0) + (0 if opt.no_instance else 1)
+    opt.gpu_ids = [int(s) for s in str(opt.gpu_ids).split(",") if int(s) >= 0]
+    return opt
+
+
+# README "Training New Models" command (README.md:60) minus dataset paths, plus --no_lab_loss (loss.py:443 does
+# `1 - mask` on a bool tensor, which torch >= 1.2 rejects; the Lab loss is outside the north-star path)
+README_TRAIN_FLAGS = ("--no_confidence_loss --no_style_loss --no_rgb_loss --no_content_loss --use_encoder --wide_edge 2 "
+                      "--no_background_loss --noise_background --random_expand_mask --no_lab_loss").split()
+
+
+def write_inpaint_checkpoint(opt, seed: int = 7, gain: float = 1.0):
+    """`--use_ig` loads checkpoints/<name>/InpaintingModel_gen.pth = {'generator': state_dict} (util/util.py:245-257);
+    the pretrained file is a download, so synthesise one from a seed (SURVEY.md section 8c shim 5)."""
+    from michigan_amd.synth import synth_state_dict
+    ig = build_inpaint(opt)
+    sd = synth_state_dict(ig.state_dict(), seed=seed, gain=gain)
+    d = os.path.join(opt.checkpoints_dir, opt.name)
+    os.makedirs(d, exist_ok=True)
+    torch.save({"generator": sd}, os.path.join(d, opt.ig_model_name))
+    return sd

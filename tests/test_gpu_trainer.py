@@ -1,0 +1,47 @@
+"""MI355X: this repo's trainer on the real HIP kernels reproduces what the UNMODIFIED reference trainer produced
+(tests/golden/trainer_{A,B}.npz from `oracle/make_golden.py --trainer`): every loss of two G+D iterations, the generated
+image, updated weights, running statistics, spectral-norm vectors -- incl. the second generator forward of each iteration
+ and the frozen in-painting net under --use_ig (fixture B).  The reference-trainer-over-HIP-classes
+half of the chain runs where the reference checkout exists (tests/test_dropin.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import trainer_parity as TP
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _run(tag, dtype):
+    from michigan_amd.model import Pix2PixTrainer
+    cfg = TP.CFGS[tag]
+    torch.manual_seed(0)
+    trainer = Pix2PixTrainer(TP.repo_options(cfg, gpu_ids=[0], compute_dtype=dtype))
+    TP.load_weights(trainer, cfg)
+    rec = TP.drive(trainer, cfg, device="cuda")
+    return rec, np.load(os.path.join(GOLDEN, "trainer_%s.npz" % tag))
+
+
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_trainer_fp32_matches_reference_trainer_golden(hip_backend, tag):
+    # fp32 MFMA kernels vs the reference's fp32 ATen run: iteration 0 to 5e-4 relative on the losses and 1e-3 on the
+    # image (BASELINE target L_inf < 1e-3); behind an Adam step 1e-2 (sign-like first update, see trainer_parity.compare)
+    rec, gold = _run(tag, "fp32")
+    TP.compare(rec, gold, rtol_loss0=5e-4, rtol_later=1e-2, atol_img=1e-3, atol_weight=2 * 4e-4 * 2 + 1e-5)
+
+
+def test_trainer_bf16_tracks_reference_trainer_golden(hip_backend):
+    # bf16 activations (the benchmarked dtype), wide-range random weights: losses within 3 % at iteration 0 and 6 % behind
+    # the optimiser step, image mean |err| < 1.5e-2 (L_inf is dominated by arg-max-like flips of saturated tanh pixels)
+    rec, gold = _run("A", "bf16")
+    for k in gold.files:
+        if ".loss." in k:
+            tol = 0.03 if k.startswith("it0.") else 0.06
+            assert abs(float(rec[k]) - float(gold[k])) <= tol * max(abs(float(gold[k])), 0.1), (k, rec[k], gold[k])
+    assert np.abs(rec["it0.generated"] - gold["it0.generated"]).mean() < 1.5e-2
+    for k in gold.files:
+        if "running" in k:
+            assert np.abs(rec[k] - gold[k]).max() / np.abs(gold[k]).max() < 5e-2, k

@@ -123,3 +123,37 @@ def test_orientation_loss_matches_oracle(emulator_backend):
 def ops_bank():
     from michigan_amd import ops
     return ops.gabor_bank()
+
+
+def test_packed_weight_cache_follows_flat_adam_updates(emulator_backend):
+    """FlatAdam updates weights through a raw-pointer kernel that never bumps tensor versions; a frozen
+    (requires_grad False) parameter -- the discriminator during the generator step -- must still be re-packed after it."""
+    import torch
+    from michigan_amd import ops
+    from michigan_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(8, 8, 3, 3))
+    x = torch.randn(1, 6, 6, 8)
+    opt = FlatAdam([w], lr=0.5)
+    ref = lambda: torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.detach(), padding=1).permute(0, 2, 3, 1)
+    w.requires_grad_(False)
+    y0 = ops.conv2d(x, w, None, padding=1)
+    y0b = ops.conv2d(x, w, None, padding=1)                 # served from the cache
+    assert torch.allclose(y0, ref(), atol=1e-5) and torch.equal(y0, y0b)
+    w.requires_grad_(True)
+    w.grad.normal_()
+    opt.step()
+    w.requires_grad_(False)
+    y1 = ops.conv2d(x, w, None, padding=1)
+    assert (y1 - y0).abs().max() > 0.1                      # the weights moved by ~lr
+    assert torch.allclose(y1, ref(), atol=1e-5)
+    # torch-side in-place updates are seen through the version counter
+    with torch.no_grad():
+        w.mul_(2.0)
+    assert torch.allclose(ops.conv2d(x, w, None, padding=1), ref(), atol=1e-5)
+    # a new parameter that happens to re-use a freed address must not hit the old image
+    for _ in range(4):
+        w2 = torch.nn.Parameter(torch.randn(8, 8, 3, 3), requires_grad=False)
+        want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w2, padding=1).permute(0, 2, 3, 1)
+        assert torch.allclose(ops.conv2d(x, w2, None, padding=1), want, atol=1e-5)
+        del w2
