@@ -79,8 +79,32 @@ class ConvMeter:
         return len(self.records), ms, fl
 
 
+def self_spawn(a) -> int:
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves, exactly as the
+    driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` would, one
+    rank per GPU over RCCL, and pass rank 0's JSON line through."""
+    import socket
+    import subprocess
+    backend = os.environ.get("MG_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but only {have} GPU(s) visible (RCCL needs one GPU per rank; "
+              "MG_BENCH_BACKEND=gloo lets ranks share a GPU for a functional smoke run)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on these hosts (RCCL across processes)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -92,7 +116,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    ranks_seen = 1
+    if world > 1:
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)                                   # every rank really is in the job (and RCCL is up before the timed region)
+        ranks_seen = int(ones.item())
 
     from michigan_amd import _cabi
     from michigan_amd.model import Pix2PixTrainer, default_options
@@ -138,9 +168,12 @@ def main():
     if not a.no_roofline:
         # one extra, untimed step with HIP-event timing of every conv launch.  EVERY rank runs it (the step
         # contains collectives); only rank 0 reports.
+        from michigan_amd import parallel as _par
+        _par.reset_collective_counts()
         with ConvMeter() as m:
             step()
         n, ms, fl = m.summary()
+        collectives = dict(_par.COLLECTIVES)
         if rank == 0:
             peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
             ach = fl / (ms * 1e-3) / 1e12
@@ -163,7 +196,7 @@ def main():
         out = {
             "metric": "training images/sec at 512x512 (G+D step)" if a.mode == "train" else "generator forward images/sec at 512x512",
             "value": round(value, 3), "unit": "images/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
+            "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if a.dtype == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": (f"SPADEB G + multiscale PatchGAN D + VGG19 + Gabor orientation losses, full G step + D step (Adam), "
@@ -178,6 +211,8 @@ def main():
                                       "gflop_per_image": [step_gflop_ref, step_gflop_min], "unit": "TFLOP/s per GPU"},
             "losses": losses,
         }
+        if roof is not None and world > 1:
+            out["collectives_per_step"] = collectives          # RCCL all-reduces one rank issues per G+D step, by kind
         if roof is not None:
             out["roofline"] = roof
         if world == 1 and not a.no_cpu_baseline and a.mode == "train":

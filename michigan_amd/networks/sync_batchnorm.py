@@ -78,17 +78,16 @@ class SynchronizedBatchNorm2d(nn.Module):
 
 
 class DataParallelWithCallback(nn.Module):
-    """Drop-in for the name the trainer imports (pix2pix_trainer.py:6,21-24): exposes `.module`
-    and forwards calls.  Data parallelism itself is process-per-GPU (michigan_amd.parallel):
-    this wrapper registers the module with the gradient all-reducer when a process group exists,
-    so `DataParallelWithCallback(model, device_ids=opt.gpu_ids)` keeps working unchanged."""
+    """The name the reference trainer imports (pix2pix_trainer.py:6,21-24): exposes `.module` and forwards calls --
+    nothing else.  Data parallelism here is one PROCESS per GPU: cross-rank batch-norm statistics are switched on by
+    `michigan_amd.parallel.init()` (ops.SYNC_BN_GROUP) and gradient averaging belongs to the optimiser
+    (`michigan_amd.optim.FlatAdam(group=...)`, bucketed in-place all-reduce from post-accumulate hooks), so there is no
+    replication, scatter or gather for this wrapper to do; `device_ids` is accepted and ignored beyond its first entry."""
 
     def __init__(self, module, device_ids=None):
         super().__init__()
         self.module = module
         self.device_ids = list(device_ids) if device_ids is not None else []
-        from .. import parallel
-        self.reducer = parallel.attach(module)
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

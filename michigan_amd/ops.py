@@ -436,6 +436,7 @@ def batch_stats_begin(x: torch.Tensor):
         if SYNC_BN_GROUP is not None:
             import torch.distributed as dist
             work = dist.all_reduce(sums, group=SYNC_BN_GROUP, async_op=True)
+            _count_collective("syncbn_fwd")
             count *= dist.get_world_size(SYNC_BN_GROUP)
         return sums, work, count, c
 
@@ -475,6 +476,11 @@ def advance_running_stats(sums: torch.Tensor, count, eps: float, momentum: float
     scratch = torch.empty(2 * c, dtype=torch.float32, device=sums.device)
     C.backend().mg_norm_finalize(_p(sums), 1, c, float(count), eps, momentum, _p(running_mean), _p(running_var),
                                  _p(scratch[:c]), _p(scratch[c:]), _stream(sums))
+
+
+def _count_collective(kind: str):
+    from . import parallel
+    parallel.COLLECTIVES[kind] += 1
 
 
 def _interleave32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -535,6 +541,7 @@ class _SpadeFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] and SYNC_BN_GROUP is not None:
             import torch.distributed as dist
             work = dist.all_reduce(sums, group=SYNC_BN_GROUP, async_op=True)    # overlaps with the gamma/beta conv's backward below
+            _count_collective("syncbn_bwd")
         if ctx.needs_input_grad[1]:
             wt = pack_weight(w_gamma, w_beta, x.dtype, _roundup(actv.shape[3], 128), rows, 1)
             dactv = conv_dgrad(dgb, wt, kh, kh, 1, pad, (hh, ww), actv.shape[3],

@@ -97,6 +97,8 @@ class FlatAdam:
     def _launch(self, i):
         lo, hi, _ = self.buckets[i]
         chunk = self.flat_grad[lo:hi]
+        from . import parallel
+        parallel.COLLECTIVES["grad_bucket"] += 1
         if chunk.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=chunk.device)

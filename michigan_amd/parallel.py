@@ -14,8 +14,6 @@ has been produced (autograd post-accumulate hooks), overlapping with the remaini
 from __future__ import annotations
 
 import os
-from typing import List, Optional
-
 import torch
 import torch.distributed as dist
 
@@ -44,96 +42,13 @@ def world_size() -> int:
     return dist.get_world_size(_GROUP) if _GROUP is not None else 1
 
 
-class GradReducer:
-    """Bucketed, overlapped gradient averaging for one set of parameters (one optimiser)."""
-
-    def __init__(self, params, bucket_bytes: int = 64 << 20, group=None):
-        self.group = group if group is not None else _GROUP
-        self.params = [p for p in params if p.requires_grad]
-        self.world = dist.get_world_size(self.group) if self.group is not None else 1
-        self.buckets: List[List[torch.nn.Parameter]] = []
-        cur, size = [], 0
-        for p in reversed(self.params):                 # backward produces grads roughly in reverse order
-            cur.append(p)
-            size += p.numel() * 4
-            if size >= bucket_bytes:
-                self.buckets.append(cur)
-                cur, size = [], 0
-        if cur:
-            self.buckets.append(cur)
-        self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
-        self._pending = [0] * len(self.buckets)
-        self._work = []
-        self._stream: Optional[torch.cuda.Stream] = None
-        self._hooks = []
-        self.enabled = True
-        if self.world > 1:
-            for p in self.params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
-        self.reset()
-
-    def reset(self):
-        self._pending = [len(b) for b in self.buckets]
-        self._work = []
-
-    def _on_grad(self, p):
-        if not self.enabled:
-            return
-        i = self._bucket_of[id(p)]
-        self._pending[i] -= 1
-        if self._pending[i] == 0:
-            self._launch(i)
-
-    def _launch(self, i, only_ready=False):
-        grads = [p.grad for p in self.buckets[i] if p.grad is not None]
-        if not grads:
-            return
-        dev = grads[0].device
-        if dev.type == "cuda":
-            if self._stream is None:
-                self._stream = torch.cuda.Stream(device=dev)
-            self._stream.wait_stream(torch.cuda.current_stream(dev))
-            ctx = torch.cuda.stream(self._stream)
-        else:
-            import contextlib
-            ctx = contextlib.nullcontext()
-        with ctx:
-            flat = torch.cat([g.reshape(-1) for g in grads])
-            work = dist.all_reduce(flat, group=self.group, async_op=True)
-        self._work.append((work, flat, grads))
-
-    def finish(self):
-        """Call after backward(): flush buckets holding never-produced grads (e.g. the generator's
-        unused backgroud_enc.layer4), wait for the collectives, write averaged grads back."""
-        if self.world == 1:
-            return
-        for i, left in enumerate(self._pending):
-            if left > 0:
-                self._pending[i] = 0
-                self._launch(i)
-        for work, flat, grads in self._work:
-            work.wait()
-            dev = flat.device
-            ctx = torch.cuda.stream(self._stream) if dev.type == "cuda" else None
-            if ctx is not None:
-                ctx.__enter__()
-            try:
-                flat.div_(self.world)
-                off = 0
-                for g in grads:
-                    g.copy_(flat[off:off + g.numel()].view_as(g))
-                    off += g.numel()
-            finally:
-                if ctx is not None:
-                    ctx.__exit__(None, None, None)
-        if self._stream is not None:
-            torch.cuda.current_stream().wait_stream(self._stream)
-        self.reset()
+# collectives issued since the last reset, by kind (bench.py reports them per step)
+COLLECTIVES = {"syncbn_fwd": 0, "syncbn_bwd": 0, "grad_bucket": 0}
 
 
-def attach(module):
-    """Hook used by DataParallelWithCallback: returns None in single-process runs."""
-    return None
+def reset_collective_counts():
+    for k in COLLECTIVES:
+        COLLECTIVES[k] = 0
 
 
 def broadcast_parameters(module, src: int = 0, group=None):

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _one_step(rank, world, port, n_total, q):
+def _one_step(rank, world, port, n_total, q, bucket_bytes=1 << 18):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     torch.set_num_threads(2)
@@ -42,7 +42,7 @@ def _one_step(rank, world, port, n_total, q):
     opt = PU.small_opt(ngf=8, crop_size=128)
     G = networks.SPADEBGenerator(opt).train()
     G.load_state_dict(synth_state_dict(G.state_dict(), seed=31, gain=1.0))
-    optim = FlatAdam(G.parameters(), lr=1e-3, betas=(0.0, 0.9), bucket_bytes=1 << 18, group=group)
+    optim = FlatAdam(G.parameters(), lr=1e-3, betas=(0.0, 0.9), bucket_bytes=bucket_bytes, group=group)
     full = synth_batch(n_total, 128, seed=17)
     per = n_total // world
     b = {k: v[rank * per:(rank + 1) * per] for k, v in full.items()}
@@ -54,13 +54,15 @@ def _one_step(rank, world, port, n_total, q):
                 noise=b["noise"], image_tag=b["image_tag"])
         ((out * gy).sum() / per).backward()
         if it == 0:
+            untouched = [i for i, (left, b) in enumerate(zip(optim._pending, optim.buckets)) if left == b[2]]   # no gradient arrived at all
             optim.sync_grads()                      # summed over ranks; the 1/world average is applied inside Adam
             grad0 = (optim.flat_grad / world).numpy().copy()
             out0 = out.detach().numpy().copy()
             rm0 = G.state_dict()["up_3.norm_1.param_free_norm.running_mean"].numpy().copy()
             rv0 = G.state_dict()["head_0.norm_0.param_free_norm.running_var"].numpy().copy()
         optim.step()
-    res = {"grad0": grad0, "flat": optim.flat.detach().numpy().copy(), "out": out0, "rm": rm0, "rv": rv0}      # numpy: plain pickling
+    res = {"grad0": grad0, "flat": optim.flat.detach().numpy().copy(), "out": out0, "rm": rm0, "rv": rv0,      # numpy: plain pickling
+           "untouched": untouched, "nbuckets": len(optim.buckets)}
     q.put((rank, res))
     if world > 1:
         dist.barrier()
@@ -80,8 +82,9 @@ def test_two_ranks_equal_single_process_on_concatenated_batch():
     for p in procs:
         p.start()
     got = dict(q.get(timeout=600) for _ in range(2))
-    single = {k: torch.from_numpy(v) for k, v in single.items()}
-    got = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in got.items()}
+    arrays = lambda d: {k: torch.from_numpy(v) for k, v in d.items() if hasattr(v, "dtype")}
+    single = arrays(single)
+    got = {r: arrays(d) for r, d in got.items()}
     for p in procs:
         p.join()
         assert p.exitcode == 0
@@ -98,6 +101,37 @@ def test_two_ranks_equal_single_process_on_concatenated_batch():
     assert (out2 - single["out"]).abs().max().item() < 5e-5
     for k in ("rm", "rv"):
         assert torch.allclose(got[0][k], got[1][k]) and (got[0][k] - single[k]).abs().max().item() < 1e-5
+
+
+@pytest.mark.timeout(1200)
+def test_four_ranks_with_never_produced_gradient_buckets():
+    """world_size 4, one image per rank, 16 KiB buckets: several buckets hold only parameters that never receive a
+    gradient (the reference's unused backgroud_enc.layer4, encoder.py:283-285) -- no hook ever fires for them, so they
+    must be flushed by sync_grads on every rank in the same order or the collectives would mismatch / hang."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_step, args=(0, 1, 0, 4, q, 1 << 14))
+    p.start()
+    _, single = q.get(timeout=600)
+    p.join()
+    port = _free_port()
+    procs = [ctx.Process(target=_one_step, args=(r, 4, port, 4, q, 1 << 14)) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=900) for _ in range(4))
+    for p in procs:
+        p.join()
+        assert p.exitcode == 0
+    assert got[0]["nbuckets"] > 20 and len(got[0]["untouched"]) >= 1           # the case under test really occurred
+    for r in range(1, 4):
+        assert got[r]["untouched"] == got[0]["untouched"]
+        assert (got[r]["flat"] == got[0]["flat"]).all() and (got[r]["grad0"] == got[0]["grad0"]).all()
+    g, s = torch.from_numpy(got[0]["grad0"]), torch.from_numpy(single["grad0"])
+    assert (g - s).abs().max().item() < 1e-4 * s.abs().max().item()
+    out4 = torch.cat([torch.from_numpy(got[r]["out"]) for r in range(4)])
+    assert (out4 - torch.from_numpy(single["out"])).abs().max().item() < 5e-5
+    for k in ("rm", "rv"):
+        assert abs(got[0][k] - single[k]).max() < 1e-5
 
 
 def _trainer_step(rank, world, port, n_total, q):
