@@ -221,6 +221,18 @@ int mg_unpack_wgrad(const float* dw, float* d0, float* d1, int32_t cout, int32_t
 int mg_l1_mean_fwd(const void* a, const void* b, int32_t dtype, int64_t numel, float* out, float* partial, void* stream);
 int mg_l1_mean_bwd(const void* a, const void* b, const float* gscale, int32_t dtype, int64_t numel, void* da, void* stream);
 
+/* Hinge GAN loss on a patch discriminator's 1-channel logit map with the wide-edge weight mask (loss.py:60-140).
+ * mg_wide_edge_weight: label fp32 [N][Hl][Wl] in {0,1} -> weight fp32 [N][h][w] = e * wide + (1 - e), e = get_wide_edges of
+ *   the label resized (nearest) to h x w with window k (= max(1, int(h * 0.06)), padding k / 2), resized back (nearest) from
+ *   the pooled (h + 2(k/2) - k + 1)^2 map; depends only on the label: build once per batch and logit resolution.
+ * mg_hinge_fwd: out[0] = -mean(f(x) * weight), x = n logits in `dtype`, weight fp32 or NULL (= 1);
+ *   mode 0: f = x (generator), 1: f = min(x - 1, 0) (discriminator, real), 2: f = min(-x - 1, 0) (discriminator, fake).
+ * mg_hinge_bwd: dx = -g[0] / n * f'(x) * weight in `dtype`. */
+int mg_wide_edge_weight(const float* label, int32_t N, int32_t Hl, int32_t Wl, int32_t h, int32_t w, int32_t k, float wide,
+                        float* out, void* stream);
+int mg_hinge_fwd(const void* x, const float* weight, int32_t dtype, int64_t n, int32_t mode, float* out, void* stream);
+int mg_hinge_bwd(const void* x, const float* weight, const float* g, int32_t dtype, int64_t n, int32_t mode, void* dx, void* stream);
+
 /* Orientation-loss filter bank (loss.py:274-313: 32 oriented 17x17 Gabor filters on the gray image, clamp at 0,
  * max / arg-max over the 32 responses).  img is NHWC with C >= 3 (RGB in [-1,1] in channels 0..2); bank is
  * fp32 [32][17][17]; conf[N][H][W] = max_k max(resp_k, 0), idx[N][H][W] = first arg-max (u8).  The contraction

@@ -70,6 +70,9 @@ _PROTOS = {
     "mg_unpack_wgrad": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_l1_mean_fwd": ([_vp, _vp, _i32, _i64, _vp, _vp, _vp], _i32),
     "mg_l1_mean_bwd": ([_vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
+    "mg_wide_edge_weight": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp], _i32),
+    "mg_hinge_fwd": ([_vp, _vp, _i32, _i64, _i32, _vp, _vp], _i32),
+    "mg_hinge_bwd": ([_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp], _i32),
     "mg_gabor_argmax_fwd": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_gabor_argmax_bwd": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_sn_normalize": ([_vp, _i32, _f32, _vp, _vp, _vp, _vp], _i32),

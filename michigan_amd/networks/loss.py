@@ -1,9 +1,9 @@
 """Losses that consume the hot path's outputs (reference: models/networks/loss.py:19-207).
 
-Reductions run in fp32 on whatever dtype the discriminator / VGG towers produced.  Only the
-loss classes on the BASELINE path are provided (hinge GAN loss with wide-edge weighting,
-discriminator feature matching, VGG perceptual loss); orientation / Lab / style losses are out of
-scope."""
+Reductions run in fp32 on whatever dtype the discriminator / VGG towers produced, as fused HIP launches: the hinge GAN
+loss with its wide-edge weight mask (mg_hinge_*, mg_wide_edge_weight), discriminator feature matching and the VGG taps
+(mg_l1_mean_*), the Gabor orientation loss (mg_gabor_argmax_*).  Lab / style / background losses are out of scope
+ and stay the reference's own classes under michigan_amd.dropin."""
 from __future__ import annotations
 
 import math
@@ -37,17 +37,24 @@ class GANLoss(nn.Module):
         edges = self.get_wide_edges(label)
         return edges * self.opt.wide_edge + (1 - edges)
 
+    def weight_mask(self, input, label):
+        """get_weight_mask (loss.py:82-89) for one logit resolution as ONE HIP launch (index work on a 67x67 / 35x35 map)."""
+        return ops.wide_edge_weight(label, input.shape[2], input.shape[3], self.opt.wide_edge)
+
     def loss(self, input, target_is_real, for_discriminator=True, label=None):
-        input = input.float()
         if self.gan_mode == "original":
+            input = input.float()
             target = torch.full_like(input, self.real_label if target_is_real else self.fake_label)
             return F.binary_cross_entropy_with_logits(input, target)
         if self.gan_mode == "ls":
+            input = input.float()
             target = torch.full_like(input, self.real_label if target_is_real else self.fake_label)
             return F.mse_loss(input, target)
         if self.gan_mode == "w":
+            input = input.float()
             return -input.mean() if target_is_real else input.mean()
         if getattr(self.opt, "remove_background", False):
+            input = input.float()
             c = input.shape[1]
             lab = F.interpolate(label, size=input.shape[2:], mode="nearest")
             denom = lab.sum() * c + 1e-5
@@ -56,9 +63,15 @@ class GANLoss(nn.Module):
                 return -(input * lab).sum() / denom
             margin = ((input - 1) if target_is_real else (-input - 1)) * lab
             return -torch.clamp_max(margin, 0).sum() / denom
+        # hinge (loss.py:96-111): one fused launch per logit map (+ one per batch and resolution for the weight mask)
+        fused = input.dtype in (torch.float32, torch.bfloat16) and (input.shape[1] == 1 or input.is_contiguous())
         if not for_discriminator:
             assert target_is_real, "The generator's hinge loss must be aiming for real"
-            return -input.mean()
+            return ops.hinge_loss(input, None, ops.HINGE_G) if fused else -input.float().mean()
+        if fused and (self.opt.wide_edge <= 1.0 or input.shape[1] == 1):
+            wm = self.weight_mask(input, label) if self.opt.wide_edge > 1.0 else None
+            return ops.hinge_loss(input, wm, ops.HINGE_D_REAL if target_is_real else ops.HINGE_D_FAKE)
+        input = input.float()
         margin = torch.clamp_max((input - 1) if target_is_real else (-input - 1), 0)
         if self.opt.wide_edge > 1.0:
             margin = margin * self.get_weight_mask(input, label)

@@ -849,6 +849,49 @@ def l1_mean(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return _L1MeanFn.apply(a, b)
 
 
+class _HingeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, mode):
+        n = x.numel()
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        C.backend().mg_hinge_fwd(_p(x), _p(weight), _dt(x), n, mode, _p(out), _stream(x))
+        ctx.save_for_backward(x, weight)
+        ctx.mode = mode
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.reshape(1).float().contiguous()
+        dx = torch.empty_like(x)
+        C.backend().mg_hinge_bwd(_p(x), _p(weight), _p(g), _dt(x), x.numel(), ctx.mode, _p(dx), _stream(x))
+        return dx, None, None
+
+
+HINGE_G, HINGE_D_REAL, HINGE_D_FAKE = 0, 1, 2
+
+
+def hinge_loss(logits: torch.Tensor, weight: Optional[torch.Tensor], mode: int) -> torch.Tensor:
+    """-mean(f(logits) * weight) of a patch discriminator's logit map (any shape, dense), one launch forward and one
+    backward: f = x (HINGE_G), min(x - 1, 0) (HINGE_D_REAL), min(-x - 1, 0) (HINGE_D_FAKE)  (loss.py:96-111)."""
+    x = logits if logits.is_contiguous() else _dense_view(logits)
+    if weight is not None and (weight.numel() != x.numel() or weight.dtype != torch.float32):
+        raise ValueError("hinge_loss: weight must be fp32 with one value per logit")
+    return _HingeFn.apply(x, weight.contiguous() if weight is not None else None, mode)
+
+
+def wide_edge_weight(label: torch.Tensor, h: int, w: int, wide: float, th: float = 0.06) -> torch.Tensor:
+    """GANLoss.get_weight_mask (loss.py:60-89) for one logit resolution: label [N,1,Hl,Wl] in {0,1} -> fp32 [N,1,h,w]."""
+    label = label.detach().float().contiguous()
+    n, c, hl, wl = label.shape
+    if c != 1:
+        raise ValueError("wide_edge_weight: the label must have one channel")
+    k = max(1, int(h * th))
+    out = torch.empty((n, 1, h, w), dtype=torch.float32, device=label.device)
+    C.backend().mg_wide_edge_weight(_p(label), n, hl, wl, h, w, k, float(wide), _p(out), _stream(label))
+    return out
+
+
 def gabor_bank(device=None) -> torch.Tensor:
     """The 32 oriented 17x17 Gabor kernels of the orientation loss, fp32 [32, 17, 17]
     (loss.py:215-243: sigma_x 2, sigma_y 3, lambda 4, psi 0, theta_k = pi k / 32; x runs along rows)."""

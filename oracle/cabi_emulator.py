@@ -366,6 +366,44 @@ class EmulatorBackend:
         _view(da, (numel,), td)[:] = (torch.sign(av - bv) * g).to(td)
         return 0
 
+    def mg_wide_edge_weight(self, label, N, Hl, Wl, h, w, k, wide, out, stream=None):
+        """loss.py:60-80 with torch's own ops (float32 like the reference: F.interpolate's index arithmetic is float32)."""
+        import torch.nn.functional as F
+        lab = _view(label, (N, 1, Hl, Wl), torch.float32)
+        t = F.interpolate(lab, size=(h, w), mode="nearest")
+        p = int(k / 2)
+        grown = F.max_pool2d(t, kernel_size=k, stride=1, padding=p)
+        shrunk = 1 - F.max_pool2d(1 - t, kernel_size=k, stride=1, padding=p)
+        e = F.interpolate(grown - shrunk, size=(h, w), mode="nearest")
+        _view(out, (N, 1, h, w), torch.float32)[:] = e * wide + (1 - e)
+        return 0
+
+    @staticmethod
+    def _hinge_term(x, mode):
+        if mode == 0:
+            return x
+        return torch.clamp_max((x if mode == 1 else -x) - 1, 0)
+
+    def mg_hinge_fwd(self, x, weight, dtype, n, mode, out, stream=None):
+        v = self._hinge_term(_view(x, (n,), _TD[dtype]).double(), mode)
+        if _addr(weight):
+            v = v * _view(weight, (n,), torch.float32).double()
+        _view(out, (1,), torch.float32)[0] = float(-v.mean())
+        return 0
+
+    def mg_hinge_bwd(self, x, weight, g, dtype, n, mode, dx, stream=None):
+        xv = _view(x, (n,), _TD[dtype]).double()
+        if mode == 0:
+            d = torch.ones_like(xv)
+        elif mode == 1:
+            d = (xv - 1 < 0).double()
+        else:
+            d = -((-xv - 1) < 0).double()
+        if _addr(weight):
+            d = d * _view(weight, (n,), torch.float32).double()
+        _view(dx, (n,), _TD[dtype])[:] = (-float(_view(g, (1,), torch.float32)[0]) / n * d).to(_TD[dtype])
+        return 0
+
     @staticmethod
     def _gray(img):
         x = (img[..., :3].double() + 1) / 2 * 255

@@ -103,3 +103,70 @@ def test_discriminator_halves_decouple_at_512(hip_backend):
             a, b = ta[:2].float(), tb.float()
             assert (a - b).abs().max().item() <= 2.0 ** -6 * max(b.abs().max().item(), 1e-6)
     assert [tuple(t.shape[1:]) for t in both[0]] == [(64, 257, 257), (128, 129, 129), (256, 65, 65), (512, 66, 66), (1, 67, 67)]
+
+
+def test_generator_fullwidth_gradients_match_oracle_autograd(hip_backend):
+    """VERDICT r1 parity hole: the gradient goldens are ngf 16.  Here the benchmarked width (ngf 64: 1024/512-channel
+    layers, split-K forward/dgrad slices, the 3x3-row wgrad kernel with its split-K) runs fp32 forward + backward at
+    256x256, batch 2, on the HIP kernels and is compared with torch autograd through the oracle restatement on the
+    host for parameters of every kind the wide layers have (spectral-normed 3x3 at 1024 and 512 channels, a 1x1
+    shortcut, gamma / beta convs, the partial-conv encoder's 1024-channel layer, a bias).
+    Tolerance: 5e-3 of each tensor's largest gradient element (fp32 MFMA accumulation order vs oneDNN's)."""
+    from michigan_amd import networks
+    from michigan_amd.model import default_options
+    from michigan_amd.synth import synth_batch, synth_state_dict
+    from oracle import michigan_oracle as O
+    names = ["head_0.conv_0.weight_orig", "G_middle_1.conv_1.weight_orig", "up_0.conv_0.weight_orig", "up_0.conv_s.weight_orig",
+             "up_0.norm_0.mlp_gamma.weight", "up_1.norm_1.mlp_beta.weight", "head_0.norm_1.mlp_gamma.bias", "fc.layer5.weight",
+             "up_3.conv_1.bias", "up_2.norm_s.mlp_shared.0.weight", "backgroud_enc.layer3.conv.weight"]
+    opt = default_options(gpu_ids=[0], compute_dtype="fp32", random_expand_mask=False, crop_size=256)
+    torch.manual_seed(0)
+    G = networks.SPADEBGenerator(opt).train()
+    sd = synth_state_dict(G.state_dict(), seed=43, gain=1.0)
+    G.load_state_dict(sd)
+    G.cuda()
+    b = synth_batch(2, 256, seed=79)
+    gy = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(5))
+    out = _run(G, b, 2)
+    (out.float() * gy.cuda()).sum().backward()
+    got = {n: p.grad.detach().float().cpu() for n, p in G.named_parameters() if n in names}
+    assert sorted(got) == sorted(names)
+    osd = {k: (v.clone().requires_grad_() if k in names else v.clone()) for k, v in sd.items()}
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref_out = O.spadeb_generator(osd, opt, b["input_ref"], b["orient"], b["image_ref"], b["input_tag"], b["noise"], b["image_tag"], True, {})
+    (ref_out * gy).sum().backward()
+    assert (out.detach().float().cpu() - ref_out.detach()).abs().max().item() < 1e-3
+    worst = {}
+    for n in names:
+        want = osd[n].grad
+        worst[n] = ((got[n] - want).abs().max() / want.abs().max()).item()
+    print("full-width gradient errors (relative to each tensor's max):", {k: "%.1e" % v for k, v in worst.items()})
+    assert max(worst.values()) < 5e-3, worst
+
+
+def test_generator_bf16_default_init_matches_oracle_tightly(hip_backend):
+    """The benchmarked configuration: bf16 activations under the REFERENCE DEFAULT init (xavier, gain 0.02,
+    base_network.py:35-57) -- gamma, beta ~ 0, every block output O(1) after batch norm -- at full width, 256x256, batch 2,
+    against the fp32 oracle with the same weights.  SURVEY section 8c expects ~1e-2 L_inf on the tanh image; the image itself
+    is small under this init (|out| ~ 1e-2), so the bound is stated both absolutely (< 1e-2) and relative to the image's range
+    (< 3e-2 = a few bf16 ulps accumulated over 7 blocks)."""
+    from michigan_amd import networks
+    from michigan_amd.model import default_options
+    from michigan_amd.synth import synth_batch
+    from oracle import michigan_oracle as O
+    opt = default_options(gpu_ids=[0], compute_dtype="bf16", random_expand_mask=False, crop_size=256)
+    torch.manual_seed(11)
+    G = networks.SPADEBGenerator(opt).train()
+    G.init_weights(opt.init_type, opt.init_variance)
+    sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    G.cuda().set_compute_dtype(torch.bfloat16)
+    b = synth_batch(2, 256, seed=81)
+    with torch.no_grad():
+        out = _run(G, b, 2).float().cpu()
+        torch.set_num_threads(min(32, torch.get_num_threads()))
+        ref = O.spadeb_generator(sd, opt, b["input_ref"], b["orient"], b["image_ref"], b["input_tag"], b["noise"], b["image_tag"], True, {})
+    err = (out - ref).abs()
+    rng = ref.abs().max().item()
+    print("bf16 default-init generator: L_inf %.3e mean %.3e, image range %.3e" % (err.max().item(), err.mean().item(), rng))
+    assert err.max().item() < 1e-2
+    assert err.max().item() < 3e-2 * rng

@@ -622,3 +622,45 @@ def test_wide_epilogue_stores_are_bit_identical_to_quad_stores(epi):
             be.mg_set_option(7, 1)
     for a, b_ in zip(*outs):
         assert torch.equal(a.view(torch.int16), b_.view(torch.int16))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_hinge_loss_and_wide_edge_weight_fused(dt):
+    """mg_wide_edge_weight (bit-exact vs the reference's interpolate / max_pool2d formula, incl. the
+    even-window (h + 1)^2 pooled map and non-square label sizes) and mg_hinge_fwd/bwd in the three modes, plus the GANLoss
+    module on a [fake | real] pair against the plain-torch restatement of loss.py:60-140."""
+    import argparse
+    import torch.nn.functional as F
+    from michigan_amd import networks, ops
+    g = torch.Generator().manual_seed(31)
+    label = (torch.rand(3, 1, 96, 80, generator=g) > 0.55).float()
+    for (h, w) in ((67, 67), (35, 35), (66, 52), (17, 19), (8, 8)):
+        x = (torch.randn(3, 1, h, w, generator=g) * 1.5).to(DT[dt]).requires_grad_()
+
+        def fn(x, label):
+            wm = ops.wide_edge_weight(label, h, w, 2.0)
+            outs = [wm]
+            for mode in (ops.HINGE_G, ops.HINGE_D_REAL, ops.HINGE_D_FAKE):
+                loss = ops.hinge_loss(x, None if mode == ops.HINGE_G else wm, mode)
+                (gx,) = torch.autograd.grad(loss * 2.0, x)
+                outs += [loss.reshape(1), gx]
+            return outs
+        (hip, _), (ref, _) = _both(fn, (x, label))
+        assert torch.equal(hip[0].cpu(), ref[0]), (h, w)                       # index / byte work: bit-exact
+        for i in (1, 3, 5):
+            _close(f"hinge {dt} loss {h}x{w} mode {i // 2}", hip[i], ref[i], 1e-5)
+            _close(f"hinge {dt} grad {h}x{w} mode {i // 2}", hip[i + 1], ref[i + 1], TOL[dt])
+    # the module, as pix2pix_model.py:571-575 calls it, vs plain torch
+    opt = argparse.Namespace(wide_edge=2.0, remove_background=False)
+    crit = networks.GANLoss("hinge", opt=opt)
+    preds = [[(torch.randn(4, 1, s, s, generator=g)).to(DT[dt]).cuda()] for s in (67, 35)]
+    lab = (torch.rand(4, 1, 128, 128, generator=g) > 0.5).float().cuda()
+    got = crit(preds, False, for_discriminator=True, label=lab)
+    want = 0
+    for (p,) in preds:
+        s = p.shape[2]
+        k = max(1, int(s * 0.06)); pd = int(k / 2)
+        t = F.interpolate(lab, size=(s, s), mode="nearest")
+        e = F.interpolate(F.max_pool2d(t, k, 1, pd) - (1 - F.max_pool2d(1 - t, k, 1, pd)), size=(s, s), mode="nearest")
+        want = want + -(torch.clamp_max(-p.float() - 1, 0) * (e * 2.0 + (1 - e))).mean()
+    assert abs(float(got) - float(want) / 2) < 1e-5

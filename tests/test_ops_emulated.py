@@ -157,3 +157,30 @@ def test_packed_weight_cache_follows_flat_adam_updates(emulator_backend):
         want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w2, padding=1).permute(0, 2, 3, 1)
         assert torch.allclose(ops.conv2d(x, w2, None, padding=1), want, atol=1e-5)
         del w2
+
+
+def test_hinge_and_wide_edge_match_reference_formula(emulator_backend):
+    """f1: the fused hinge / wide-edge ops (on the contract emulator here, on the HIP kernels in tests/test_gpu_kernels.py)
+    against the reference formula written with plain torch ops (loss.py:60-111), values and gradients."""
+    import torch
+    import torch.nn.functional as F
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(3)
+    label = (torch.rand(2, 1, 64, 64, generator=g) > 0.6).float()
+    for h in (67, 35, 19, 9):
+        x = torch.randn(2, 1, h, h, generator=g).requires_grad_()
+        k = max(1, int(h * 0.06)); p = int(k / 2)
+        t = F.interpolate(label, size=(h, h), mode="nearest")
+        e = F.interpolate(F.max_pool2d(t, k, 1, p) - (1 - F.max_pool2d(1 - t, k, 1, p)), size=(h, h), mode="nearest")
+        wref = e * 2.0 + (1 - e)
+        w = ops.wide_edge_weight(label, h, h, 2.0)
+        assert torch.equal(w, wref), h
+        for mode, f in ((ops.HINGE_G, lambda v: v), (ops.HINGE_D_REAL, lambda v: torch.clamp_max(v - 1, 0)),
+                        (ops.HINGE_D_FAKE, lambda v: torch.clamp_max(-v - 1, 0))):
+            ww = None if mode == ops.HINGE_G else w
+            got = ops.hinge_loss(x, ww, mode)
+            want = -(f(x) * (1 if ww is None else wref)).mean()
+            assert abs(float(got) - float(want)) < 1e-6
+            gg, = torch.autograd.grad(got * 3.0, x)
+            gw, = torch.autograd.grad(want * 3.0, x)
+            assert (gg - gw).abs().max() < 1e-7
