@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 1
+#define MG_ABI_VERSION 2
 
 enum { MG_F32 = 0, MG_BF16 = 1 };
 enum { MG_ACT_NONE = 0, MG_ACT_RELU = 1, MG_ACT_LRELU = 2, MG_ACT_TANH = 3 };
@@ -220,6 +220,28 @@ int mg_unpack_wgrad(const float* dw, float* d0, float* d1, int32_t cout, int32_t
  * workspace, out = 1 float); backward da = sign(a - b) * gscale[0] / numel (b is a constant). */
 int mg_l1_mean_fwd(const void* a, const void* b, int32_t dtype, int64_t numel, float* out, float* partial, void* stream);
 int mg_l1_mean_bwd(const void* a, const void* b, const float* gscale, int32_t dtype, int64_t numel, void* da, void* stream);
+
+/* Batched drain of GEMM-order weight gradients into reference-layout gradients (one call per optimiser step instead of a
+ * fill + unpack + spectral-norm backward + accumulate chain per convolution).  mg_conv_wgrad ACCUMULATES (fp32 atomics) into
+ * `gemm` / `dbias_gemm`, which therefore may live in a persistent arena; this call adds every slot's gradient to its
+ * destination tensor(s) and leaves the drained GEMM memory zeroed:
+ *   dst0[co][ci][t] (+ dst1 for the beta tensor of a fused SPADE gamma|beta pair, rows interleaved in blocks of 32)
+ *       += gemm[t][row(co)][ci]                                   plain
+ *       += (gemm[..] - s * u[co] * v[ci*taps + t]) / sigma[0]     spectral norm (w_sn != NULL), s = sum(gemm * w_sn)
+ *   dbias0/1[co] += dbias_gemm[row(co)]
+ * `swapped`: the GEMM image is [t][ci][row] (weight gradient computed with the operand roles exchanged).
+ * `s` = one zero-initialised double per spectral-normed slot.  The table lives in device memory; `first_block` = running sum
+ * of mg_grad_slot_blocks over the preceding slots and block_slot[b] = slot that owns workgroup b (host-built). */
+typedef struct mg_grad_slot {
+    float* gemm; float* dbias_gemm;
+    float* dst0; float* dst1; float* dbias0; float* dbias1;
+    const float* w_sn; const float* u; const float* v; const float* sigma; double* s;
+    int32_t cout, cin, taps, rows, cols, swapped;
+    int64_t first_block;
+} mg_grad_slot;
+int     mg_grad_drain(const mg_grad_slot* table_dev, int32_t nslots, const int32_t* block_slot_dev, int32_t nblocks,
+                      int32_t has_sn, void* stream);
+int64_t mg_grad_slot_blocks(int32_t cout, int32_t cin, int32_t ntens);        /* workgroups slot needs (host helper) */
 
 /* Hinge GAN loss on a patch discriminator's 1-channel logit map with the wide-edge weight mask (loss.py:60-140).
  * mg_wide_edge_weight: label fp32 [N][Hl][Wl] in {0,1} -> weight fp32 [N][h][w] = e * wide + (1 - e), e = get_wide_edges of

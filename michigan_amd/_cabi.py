@@ -15,7 +15,7 @@ MG_F32, MG_BF16 = 0, 1
 MG_ACT_NONE, MG_ACT_RELU, MG_ACT_LRELU, MG_ACT_TANH = 0, 1, 2, 3
 MG_EPI_PLAIN, MG_EPI_SPADE = 0, 1
 MG_MAX_TAPS = 64
-MG_ABI_VERSION = 1
+MG_ABI_VERSION = 2
 
 _i32, _f32, _vp, _i64 = ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
 
@@ -45,6 +45,16 @@ class WgradDesc(ctypes.Structure):
     ]
 
 
+class GradSlot(ctypes.Structure):
+    """struct mg_grad_slot (include/michigan_hip.h): one entry of the device-resident table mg_grad_drain walks."""
+    _fields_ = [
+        ("gemm", _vp), ("dbias_gemm", _vp), ("dst0", _vp), ("dst1", _vp), ("dbias0", _vp), ("dbias1", _vp),
+        ("w_sn", _vp), ("u", _vp), ("v", _vp), ("sigma", _vp), ("s", _vp),
+        ("cout", _i32), ("cin", _i32), ("taps", _i32), ("rows", _i32), ("cols", _i32), ("swapped", _i32),
+        ("first_block", _i64),
+    ]
+
+
 # name -> (argtypes, restype); descriptors are passed by reference.
 _PROTOS = {
     "mg_conv_taps": ([ctypes.POINTER(ConvDesc), _vp], _i32),
@@ -70,6 +80,8 @@ _PROTOS = {
     "mg_unpack_wgrad": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_l1_mean_fwd": ([_vp, _vp, _i32, _i64, _vp, _vp, _vp], _i32),
     "mg_l1_mean_bwd": ([_vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
+    "mg_grad_drain": ([_vp, _i32, _vp, _i32, _i32, _vp], _i32),
+    "mg_grad_slot_blocks": ([_i32, _i32, _i32], _i64),
     "mg_wide_edge_weight": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp], _i32),
     "mg_hinge_fwd": ([_vp, _vp, _i32, _i64, _i32, _vp, _vp], _i32),
     "mg_hinge_bwd": ([_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp], _i32),
@@ -99,7 +111,7 @@ _PROTOS = {
     "mg_last_error": ([], ctypes.c_char_p),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
-_NO_STATUS = {"mg_stats_workspace", "mg_sizeof_desc", "mg_abi_version", "mg_last_error", "mg_noise_field_len", "mg_bicubic_ksize"}
+_NO_STATUS = {"mg_grad_slot_blocks", "mg_stats_workspace", "mg_sizeof_desc", "mg_abi_version", "mg_last_error", "mg_noise_field_len", "mg_bicubic_ksize"}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmichigan_hip.so")
 
@@ -129,8 +141,9 @@ class HipBackend:
             f.argtypes, f.restype = argtypes, restype
         if self._lib.mg_abi_version() != MG_ABI_VERSION:
             raise RuntimeError("libmichigan_hip.so ABI version mismatch")
-        if self._lib.mg_sizeof_desc(0) != ctypes.sizeof(ConvDesc) or self._lib.mg_sizeof_desc(1) != ctypes.sizeof(WgradDesc):
-            raise RuntimeError("ctypes mirror of mg_conv_desc / mg_wgrad_desc is out of sync with the header")
+        if (self._lib.mg_sizeof_desc(0) != ctypes.sizeof(ConvDesc) or self._lib.mg_sizeof_desc(1) != ctypes.sizeof(WgradDesc)
+                or self._lib.mg_sizeof_desc(2) != ctypes.sizeof(GradSlot)):
+            raise RuntimeError("ctypes mirror of mg_conv_desc / mg_wgrad_desc / mg_grad_slot is out of sync with the header")
 
     def __getattr__(self, fn):
         if fn not in _PROTOS:

@@ -34,6 +34,9 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = C.MG_ACT_NONE, C.MG_ACT_RELU, C.MG_ACT
 WGRAD_USE_TR = True
 # Process group used to synchronise batch-norm statistics (set by michigan_amd.parallel); None = local stats.
 SYNC_BN_GROUP = None
+# Weight / bias gradients of convolutions whose parameters live in an optim.FlatAdam arena bypass autograd: the wgrad kernel
+# accumulates into the arena's persistent GEMM-order buffer and one batched launch per optimiser step drains it (optim.py).
+GRAD_SINK = True
 STATS_FROM_UPSAMPLE_SOURCE = True     # batch statistics of a 2x-upsampled tensor from its quarter-size source (A/B: tools/ab_pyflag.py)
 
 
@@ -243,12 +246,15 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, kh: int, kw: int, stride: int
     return dx
 
 
-def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int, pad: int, want_bias: bool = False):
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int, pad: int, want_bias: bool = False, out=None):
     """dW in GEMM order [T, Cg8, Cin] (fp32) of a forward conv; split-K over pixels, fp32 atomics.
-    want_bias=True also returns the bias gradient [Cg8] (column sums of dy) from the same launch."""
+    want_bias=True also returns the bias gradient [Cg8] (column sums of dy) from the same launch.
+    out = (dw, dbias): accumulate into these existing buffers (the optimiser's GEMM-order arena) instead."""
     n, h, w, cin = x.shape
     _, hj, wj, cg8 = dy.shape
-    if stride == 1 and cg8 <= 8 and cin >= 32:
+    if out is not None:
+        return _wgrad_launch(x, dy, fwd_taps(kh, kw, pad), stride, want_bias, out)
+    if _wgrad_swapped(stride, cg8, cin):
         # Few output channels (conv_img, the discriminators' 1-channel heads): a 128-row tile would be 94 % padding.
         # dW[t][co][ci] = sum_q x[q][ci] * dy[q + (pad - k_t)][co] is the weight gradient of the mirrored problem with
         # the roles of x and dy swapped, whose tiny "Cin" takes the packed-taps path; transpose the small result.
@@ -258,13 +264,22 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int,
     return _wgrad_launch(x, dy, fwd_taps(kh, kw, pad), stride, want_bias)
 
 
-def _wgrad_launch(x, dy, taps, stride, want_bias):
+def _wgrad_swapped(stride: int, cg8: int, cin: int) -> bool:
+    return stride == 1 and cg8 <= 8 and cin >= 32
+
+
+def _wgrad_launch(x, dy, taps, stride, want_bias, out=None):
     n, h, w, cin = x.shape
     _, hj, wj, cg8 = dy.shape
     ndw = len(taps) * cg8 * cin
-    buf = torch.zeros(ndw + (cg8 if want_bias else 0), dtype=torch.float32, device=x.device)    # one fill for both atomic targets
-    dw = buf[:ndw].view(len(taps), cg8, cin)
-    dbias = buf[ndw:] if want_bias else None
+    if out is not None:
+        dw, dbias = out
+        assert dw.shape == (len(taps), cg8, cin) and (dbias is not None or not want_bias)
+        dbias = dbias if want_bias else None
+    else:
+        buf = torch.zeros(ndw + (cg8 if want_bias else 0), dtype=torch.float32, device=x.device)    # one fill for both atomic targets
+        dw = buf[:ndw].view(len(taps), cg8, cin)
+        dbias = buf[ndw:] if want_bias else None
     d = C.WgradDesc()
     d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
     d.dbias = dbias.data_ptr() if want_bias else None
@@ -307,7 +322,8 @@ def act_backward(dy: torch.Tensor, y: torch.Tensor, act: int, slope: float) -> t
 # ----------------------------------------------------------------------------
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, resid, stride, pad, act, slope, x_relu=False):
+    def forward(ctx, x, weight, bias, resid, stride, pad, act, slope, x_relu=False, sink=None):
+        ctx.sink = sink
         x = _nhwc(x)
         n, h, w, cx = x.shape
         cout, cin, kh, kw = weight.shape
@@ -347,7 +363,15 @@ class _Conv2dFn(torch.autograd.Function):
             dx = conv_dgrad(dpre8, wt, kh, kw, stride, pad, (x.shape[1], x.shape[2]), cx,
                             relu_mask=x if (ctx.x_relu and FUSE_RELU_MASK) else None)
         need_b = has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
+        slot = None
+        if ctx.sink is not None and ctx.needs_input_grad[1] and not _wgrad_swapped(stride, dpre8.shape[3], cx):
+            arena, w_leaf, b_leaf, sn = ctx.sink
+            slot = arena.grad_slot(w_leaf, None, b_leaf if need_b else None, None, kh * kw, dpre8.shape[3], cx, sn)
+        if slot is not None:
+            # gradient sink: the wgrad kernel accumulates into the optimiser's GEMM-order arena; nothing goes through autograd
+            conv_wgrad(x, dpre8, kh, kw, stride, pad, want_bias=need_b, out=(slot[1], slot[2]))
+            arena.slot_written(slot[0])
+        elif ctx.needs_input_grad[1]:
             res = conv_wgrad(x, dpre8, kh, kw, stride, pad, want_bias=need_b)
             if need_b:
                 dbias = res[1][:cout]
@@ -355,7 +379,7 @@ class _Conv2dFn(torch.autograd.Function):
         elif need_b:
             dbias = channel_sums(dpre8)[0, 0, :cout]
         dres = dpre if (has_resid and ctx.needs_input_grad[3]) else None
-        return dx, dw, dbias, dres, None, None, None, None, None
+        return dx, dw, dbias, dres, None, None, None, None, None, None
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride: int = 1,
@@ -370,10 +394,27 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
         raise ValueError(f"conv2d: input has {x.shape[-1]} channels < weight Cin {weight.shape[1]}")
     xp = pad_channels(x, 8)
     y = _Conv2dFn.apply(xp, weight, bias, resid, stride, padding, act, slope,
-                        xp is x and getattr(x, "_mg_relu_out", False))
+                        xp is x and getattr(x, "_mg_relu_out", False), _sink_for(weight, bias))
     if act == ACT_RELU:
         y._mg_relu_out = True        # consumers may fold this ReLU's backward mask into their data-gradient epilogue
     return y
+
+
+def _sink_for(weight, bias, weight1=None, bias1=None):
+    """(arena, leaf weight, leaf bias, spectral-norm state) when this convolution's parameter gradients can take the
+    optimiser's gradient sink: the weight (or, under spectral norm, the `weight_orig` it was derived from -- see
+    spectral_weight) and the bias are leaf parameters of the SAME optim.FlatAdam arena.  None = autograd path."""
+    if not GRAD_SINK or not torch.is_grad_enabled():
+        return None
+    sn = getattr(weight, "_mg_sn", None)
+    leaf = sn[0] if sn is not None else weight
+    arena = getattr(leaf, "_mg_arena", None)
+    if arena is None or not arena.sink or not leaf.requires_grad:
+        return None
+    for t in (bias, weight1, bias1):
+        if t is not None and (getattr(t, "_mg_arena", None) is not arena or not t.requires_grad):
+            return None
+    return arena, leaf, bias, (sn[1:] if sn is not None else None)
 
 
 def conv2d_infer(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride: int = 1,
@@ -494,8 +535,9 @@ def _interleave32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 class _SpadeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, act, slope, actv_relu=False):
+    def forward(ctx, x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, act, slope, actv_relu=False, sink=None):
         ctx.actv_relu = bool(actv_relu)
+        ctx.sink = sink
         x, actv = _nhwc(x), _nhwc(actv)
         n, h, w, c = x.shape
         if actv.shape[:3] != x.shape[:3] or actv.dtype != x.dtype:
@@ -549,7 +591,15 @@ class _SpadeFn(torch.autograd.Function):
         need_w = ctx.needs_input_grad[2] or ctx.needs_input_grad[4]
         need_b = ctx.needs_input_grad[3] or ctx.needs_input_grad[5]
         db = None
-        if need_w:
+        slot = None
+        if ctx.sink is not None and need_w and ctx.needs_input_grad[2] and ctx.needs_input_grad[4]:
+            arena = ctx.sink[0]
+            slot = arena.grad_slot(w_gamma, w_beta, ctx.sink[2] if need_b else None, ctx.sink[3] if need_b else None,
+                                   kh * kh, rows, actv.shape[3], None)
+        if slot is not None:
+            conv_wgrad(actv, dgb, kh, kh, 1, pad, want_bias=need_b, out=(slot[1], slot[2]))
+            arena.slot_written(slot[0])
+        elif need_w:
             res = conv_wgrad(actv, dgb, kh, kh, 1, pad, want_bias=need_b)
             dwg, dwb = unpack_wgrad(res[0] if need_b else res, w_gamma.shape, two=True)
             db = res[1] if need_b else None
@@ -565,7 +615,7 @@ class _SpadeFn(torch.autograd.Function):
         if db is not None:
             db = db.reshape(rows // 64, 2, 32)
             dbg, dbb = db[:, 0].reshape(-1)[:c], db[:, 1].reshape(-1)[:c]
-        return dx, dactv, dwg, dbg, dwb, dbb, None, None, None, None, None, None
+        return dx, dactv, dwg, dbg, dwb, dbb, None, None, None, None, None, None, None
 
 
 def spade_modulate(x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, *, act=ACT_NONE, slope=0.2):
@@ -575,8 +625,9 @@ def spade_modulate(x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count,
     both to memory and makes ~12 elementwise passes).  The backward implements the full
     batch-norm gradient (statistics included), so `mean`/`rstd` enter as constants.
     """
+    sk = _sink_for(w_gamma, b_gamma, w_beta, b_beta)
     return _SpadeFn.apply(x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, act, slope,
-                          getattr(actv, "_mg_relu_out", False))
+                          getattr(actv, "_mg_relu_out", False), None if sk is None else (sk[0], sk[1], b_gamma, b_beta))
 
 
 # ----------------------------------------------------------------------------
@@ -942,6 +993,7 @@ class _SpectralScaleFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weight, u, v, sigma):
+        ctx.set_materialize_grads(False)         # a consumer on the gradient sink returns no gradient: then there is nothing to do here
         w = weight.detach().contiguous()
         out = torch.empty_like(w)
         C.backend().mg_sn_scale(_p(w), _p(sigma), _p(out), w.numel(), _stream(w))
@@ -950,6 +1002,8 @@ class _SpectralScaleFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
         w_sn, u, v, sigma = ctx.saved_tensors
         g = g.contiguous().float()
         s = torch.dot(g.reshape(-1), w_sn.reshape(-1)).reshape(1)
@@ -978,7 +1032,11 @@ def spectral_weight(weight: torch.Tensor, u: torch.Tensor, v: torch.Tensor, do_p
             sigma = torch.dot(u, torch.mv(wm, v)).reshape(1)
             uc, vc = (u.clone(), v.clone()) if need_grad else (None, None)
     if need_grad:
-        return _SpectralScaleFn.apply(weight, uc, vc, sigma)
+        w_sn = _SpectralScaleFn.apply(weight, uc, vc, sigma)
+        # lets a consuming convolution route its weight gradient through the optimiser's gradient sink, which applies this
+        # layer's sigma-backward in the batched drain (optim.FlatAdam.drain_grads) instead of _SpectralScaleFn.backward
+        w_sn._mg_sn = (weight, w_sn.detach(), uc, vc, sigma)
+        return w_sn
     out = torch.empty_like(wm).view_as(weight)
     be.mg_sn_scale(_p(weight.detach().contiguous()), _p(sigma), _p(out), weight.numel(), _stream(weight))
     return out

@@ -3,22 +3,39 @@
 MI355X-first layout: all parameters of one optimiser live in ONE contiguous fp32 buffer (the
 nn.Parameters become views of it, state_dict keys and shapes unchanged), their gradients in a
 second one.  zero_grad is one memset, Adam is one kernel over the arena (reference:
-torch.optim.Adam per tensor, pix2pix_model.py:137-145), and data-parallel gradient averaging
-all-reduces contiguous slices of the gradient arena in place -- no flatten/unflatten copies.
+torch.optim.Adam per tensor, pix2pix_model.py:137-145).
+
+Weight gradients take a short cut around autograd ("gradient sink", `ops.GRAD_SINK`): the wgrad kernels of every
+convolution whose weight lives in this arena accumulate (fp32 atomics) straight into a THIRD persistent arena in the
+kernels' GEMM order (`self.gemm`), the autograd Functions return no weight / bias gradient at all, and one batched
+launch per optimiser step (`mg_grad_drain`: un-permute, spectral-norm backward, bias rows, accumulate, re-zero) moves
+everything into the reference-layout gradient arena.  Per step that replaces ~375 small launches (zero fills, unpack,
+dot + sigma backward, autograd's accumulate adds) by two.  Data-parallel gradient averaging all-reduces contiguous
+buckets of the GEMM-order arena in place -- averaging commutes with the (linear) drain -- launched on a side stream
+as soon as the last convolution of a bucket has run its wgrad kernel; the few parameters that stay on the autograd
+path (1-channel heads, 3-channel image conv) are reduced one by one after backward.
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Optional
+import ctypes
+from typing import Dict, Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
 
+from . import _cabi as C
 from . import ops
+
+
+class _Slot:
+    """One convolution's weight (+ bias) gradient in the GEMM-order arena."""
+    __slots__ = ("index", "key", "w0", "w1", "b0", "b1", "taps", "rows", "cols", "cout", "cin", "off", "boff", "numel",
+                 "nblocks", "first_block", "sn", "written", "bucket")
 
 
 class FlatAdam:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float, betas=(0.0, 0.9), eps: float = 1e-8,
-                 bucket_bytes: int = 64 << 20, group=None):
+                 bucket_bytes: int = 64 << 20, group=None, grad_sink: Optional[bool] = None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatAdam: no trainable parameters")
@@ -29,10 +46,15 @@ class FlatAdam:
         self.group = group
         self.world = dist.get_world_size(group) if (group is not None) else 1
         self.dp = group is not None                  # world == 1 only under the MG_DP_FORCE test hook
+        self.bucket_bytes = bucket_bytes
+        self.sink = ops.GRAD_SINK if grad_sink is None else bool(grad_sink)
         self._build_arena()
+        self._work, self._stream, self._hooks = [], None, []
+        self.overlap = True
+        # ---- autograd-path buckets (all parameters when the sink is off; unused otherwise) ---------------------
         # bucket = contiguous [lo, hi) slice of the arena; params were laid out in REVERSE registration
         # order so that backward fills the arena front to back.
-        self.buckets, lo, self._bucket_of = [], 0, {}
+        self.buckets, self._bucket_of = [], {}
         per = max(bucket_bytes // 4, 1)
         cur_lo, count = 0, 0
         for p, (a, b) in zip(self._order, self._spans):
@@ -44,11 +66,21 @@ class FlatAdam:
         if count:
             self.buckets.append([cur_lo, self.flat.numel(), count])
         self._pending = [b[2] for b in self.buckets]
-        self._work, self._stream, self._hooks = [], None, []
-        self.overlap = True
+        self._leftover: List[torch.nn.Parameter] = []          # sink mode: parameters whose gradient came through autograd
         if self.dp:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        # ---- gradient sink state ------------------------------------------------------------------------------------
+        self.gemm: Optional[torch.Tensor] = None
+        self._slots: Dict[tuple, _Slot] = {}
+        self._slot_list: List[_Slot] = []
+        self._gemm_used = 0
+        self._table_host = self._table_dev = self._block_slot_dev = None
+        self._table_event = None
+        self._layout_dirty = True
+        self._gbuckets: List[List[int]] = []                     # [lo, hi, nslots] over self.gemm
+        self._gpending: List[int] = []
+        self._recording = True                                   # slot set grew during this step: no overlapped launches
 
     # ---- arenas ------------------------------------------------------------------
     def _build_arena(self):
@@ -68,25 +100,176 @@ class FlatAdam:
             p._mg_arena = self
             self._spans.append((off, off + n))
             off += n
+        self._span_of = {id(p): s for p, s in zip(self._order, self._spans)}
 
     def rebind(self):
         """Re-create the arenas after something replaced the parameters' storage (e.g. net.cpu()/net.cuda())."""
+        self.drain_grads()
         m, v = self.exp_avg, self.exp_avg_sq
         self._build_arena()
         self.exp_avg.copy_(m.to(self.exp_avg.device))
         self.exp_avg_sq.copy_(v.to(self.exp_avg.device))
         self.weight_epoch += 1
+        self.gemm, self._slots, self._slot_list, self._gemm_used, self._layout_dirty = None, {}, [], 0, True
+        self._table_host = self._table_dev = self._block_slot_dev = None
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_grad.zero_()
+        if self.gemm is not None and any(s.written for s in self._slot_list):      # a backward without a step(): discard it
+            self.gemm[:self._gemm_used].zero_()
+            self._reset_step_state()
         for p, (a, b) in zip(self._order, self._spans):                # re-attach if autograd swapped .grad
             if p.grad is None or p.grad.data_ptr() != self.flat_grad[a:b].data_ptr():
                 p.grad = self.flat_grad[a:b].view(p.shape)
         self._pending = [b[2] for b in self.buckets]
         self._work = []
+        self._leftover = []
+
+    # ---- gradient sink: GEMM-order arena ------------------------------------------------------------
+    def owns(self, p) -> bool:
+        return p is not None and getattr(p, "_mg_arena", None) is self and p.grad is not None
+
+    def grad_slot(self, w0, w1, b0, b1, taps: int, rows: int, cols: int, sn=None):
+        """Views of the GEMM-order arena for one convolution's wgrad launch: (dw [taps, rows, cols], dbias [rows] or None),
+        or None when this convolution has to stay on the autograd path.  `w1` / `b1`: the beta tensors of a fused SPADE
+        gamma|beta pair.  `sn` = (W_sn, u, v, sigma) of the forward pass this gradient belongs to (spectral norm)."""
+        if not self.sink or taps > 49 or not self.owns(w0) or (w1 is not None and not self.owns(w1)):
+            return None
+        if any(b is not None and not self.owns(b) for b in (b0, b1)):
+            return None
+        key = (id(w0), taps, rows, cols)
+        sl = self._slots.get(key)
+        if sl is None:
+            if any(k[0] == id(w0) for k in self._slots):              # same weight, another launch geometry: keep it simple
+                return None
+            sl = self._new_slot(key, w0, w1, b0, b1, taps, rows, cols)
+        if sl.written and (sl.sn is not None or sn is not None) and not self._same_sn(sl.sn, sn):
+            self.drain_grads()                                        # a second forward's (u, v, sigma): flush the first one's gradient
+        sl.sn = sn
+        dw = self.gemm[sl.off:sl.off + sl.numel].view(taps, rows, cols)
+        db = self.gemm[sl.boff:sl.boff + rows] if (b0 is not None) else None
+        return sl, dw, db
+
+    @staticmethod
+    def _same_sn(a, b):
+        if a is None or b is None:
+            return a is b
+        return all(x is y for x, y in zip(a, b))
+
+    def _new_slot(self, key, w0, w1, b0, b1, taps, rows, cols) -> _Slot:
+        if self.gemm is None:
+            # capacity: every 4-d weight at most taps * roundup(cout, 64) * roundup(cin, 8) (+ its bias rows), 256-byte slots
+            cap = 0
+            for p in self.params:
+                if p.dim() == 4:
+                    cap += p.shape[2] * p.shape[3] * ((p.shape[0] + 63) // 64 * 64) * ((p.shape[1] + 7) // 8 * 8) + 128
+                else:
+                    cap += (p.numel() + 63) // 64 * 64 + 128
+            self.gemm = torch.zeros(cap + 4096, dtype=torch.float32, device=self.flat.device)
+        sl = _Slot()
+        sl.index, sl.key = len(self._slot_list), key
+        sl.w0, sl.w1, sl.b0, sl.b1 = w0, w1, b0, b1
+        sl.taps, sl.rows, sl.cols = taps, rows, cols
+        sl.cout, sl.cin = w0.shape[0], w0.shape[1]
+        sl.numel = taps * rows * cols
+        sl.off = self._gemm_used
+        sl.boff = sl.off + (sl.numel + 63) // 64 * 64
+        end = sl.boff + ((rows + 63) // 64 * 64 if b0 is not None else 0)
+        if end > self.gemm.numel():
+            raise RuntimeError("FlatAdam: GEMM-order gradient arena exhausted (unexpected launch geometry)")
+        self._gemm_used = end
+        sl.nblocks = int(C.backend().mg_grad_slot_blocks(sl.cout, sl.cin, 2 if w1 is not None else 1))
+        sl.first_block = sum(s.nblocks for s in self._slot_list)
+        sl.sn, sl.written, sl.bucket = None, False, -1
+        self._slots[key] = sl
+        self._slot_list.append(sl)
+        self._layout_dirty = True
+        self._recording = True
+        return sl
+
+    def slot_written(self, sl: _Slot):
+        """Called by the autograd Functions right after they enqueued the wgrad kernel(s) of `sl`."""
+        first = not sl.written
+        sl.written = True
+        if self.dp and self.overlap and first and not self._recording and sl.bucket >= 0:
+            self._gpending[sl.bucket] -= 1
+            if self._gpending[sl.bucket] == 0:
+                lo, hi, _ = self._gbuckets[sl.bucket]
+                self._all_reduce(self.gemm[lo:hi])
+
+    def _freeze_layout(self):
+        """(Re)build what depends on the slot set: drain tables and the all-reduce buckets over the GEMM-order arena."""
+        dev = self.flat.device
+        block_slot = torch.empty(sum(s.nblocks for s in self._slot_list), dtype=torch.int32)
+        for s in self._slot_list:
+            block_slot[s.first_block:s.first_block + s.nblocks] = s.index
+        self._block_slot_dev = block_slot.to(dev)
+        nbytes = ctypes.sizeof(C.GradSlot) * len(self._slot_list)
+        self._table_host = torch.zeros(nbytes, dtype=torch.uint8, pin_memory=dev.type == "cuda")
+        self._table_dev = self._table_host if dev.type != "cuda" else torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._gbuckets, per, lo, n = [], max(self.bucket_bytes // 4, 1), 0, 0
+        for s in self._slot_list:
+            s.bucket = len(self._gbuckets)
+            n += 1
+            end = s.boff + ((s.rows + 63) // 64 * 64 if s.b0 is not None else 0)
+            if end - lo >= per:
+                self._gbuckets.append([lo, end, n])
+                lo, n = end, 0
+        if n:
+            self._gbuckets.append([lo, self._gemm_used, n])
+        self._gpending = [b[2] for b in self._gbuckets]
+        self._layout_dirty = False
+
+    def _reset_step_state(self):
+        for s in self._slot_list:
+            s.sn, s.written = None, False
+        self._gpending = [b[2] for b in self._gbuckets]
+        self._recording = False
+
+    def drain_grads(self):
+        """GEMM-order arena -> reference-layout gradient arena (+=), spectral-norm backward included; re-zeroes what it read."""
+        if self.gemm is None or not any(s.written for s in self._slot_list):
+            return
+        if self._layout_dirty:
+            self._freeze_layout()
+        if self._table_event is not None:
+            self._table_event.synchronize()                     # last step's upload of the table has long finished
+        tab = (C.GradSlot * len(self._slot_list)).from_address(self._table_host.data_ptr())
+        nsn = sum(1 for s in self._slot_list if s.written and s.sn is not None)
+        sdot = torch.zeros(max(nsn, 1), dtype=torch.float64, device=self.flat.device)
+        gp, fp, k = self.gemm.data_ptr(), self.flat_grad.data_ptr(), 0
+        gaddr = lambda p: fp + 4 * self._span_of[id(p)][0]
+        for s, e in zip(self._slot_list, tab):
+            e.gemm = gp + 4 * s.off
+            e.dbias_gemm = gp + 4 * s.boff if s.b0 is not None else None
+            e.dst0, e.dst1 = gaddr(s.w0), (gaddr(s.w1) if s.w1 is not None else None)
+            e.dbias0 = gaddr(s.b0) if s.b0 is not None else None
+            e.dbias1 = gaddr(s.b1) if s.b1 is not None else None
+            if s.written and s.sn is not None:
+                w_sn, u, v, sigma = s.sn
+                e.w_sn, e.u, e.v, e.sigma = w_sn.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr()
+                e.s = sdot.data_ptr() + 8 * k
+                k += 1
+            else:
+                e.w_sn = e.u = e.v = e.sigma = e.s = None
+            e.cout, e.cin, e.taps, e.rows, e.cols, e.swapped = s.cout, s.cin, s.taps, s.rows, s.cols, 0
+            e.first_block = s.first_block
+        stream = None
+        if self._table_dev is not self._table_host:
+            self._table_dev.copy_(self._table_host, non_blocking=True)
+            self._table_event = torch.cuda.Event()
+            self._table_event.record()
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.flat.device).cuda_stream)
+        C.backend().mg_grad_drain(ctypes.c_void_p(self._table_dev.data_ptr()), len(self._slot_list),
+                                  ctypes.c_void_p(self._block_slot_dev.data_ptr()), int(self._block_slot_dev.numel()),
+                                  1 if nsn else 0, stream)
+        self._reset_step_state()
 
     # ---- overlapped gradient averaging ----------------------------------------------
     def _on_grad(self, p):
+        if self.sink:
+            self._leftover.append(p)                    # reduced one by one in sync_grads (a handful of small tensors)
+            return
         if not self.overlap:
             return
         i = self._bucket_of[id(p)]
@@ -94,9 +277,7 @@ class FlatAdam:
         if self._pending[i] == 0:
             self._launch(i)
 
-    def _launch(self, i):
-        lo, hi, _ = self.buckets[i]
-        chunk = self.flat_grad[lo:hi]
+    def _all_reduce(self, chunk):
         from . import parallel
         parallel.COLLECTIVES["grad_bucket"] += 1
         if chunk.is_cuda:
@@ -108,21 +289,42 @@ class FlatAdam:
         else:
             self._work.append(dist.all_reduce(chunk, group=self.group, async_op=True))
 
+    def _launch(self, i):
+        lo, hi, _ = self.buckets[i]
+        self._all_reduce(self.flat_grad[lo:hi])
+
     def sync_grads(self):
-        """After backward(): reduce whatever has not been launched yet (buckets holding parameters that
-        received no gradient, or everything when overlap is off) and wait.  The 1/world average is
-        folded into the Adam kernel's grad_scale."""
-        if not self.dp:
-            return
-        for i, left in enumerate(self._pending):
-            if left > 0 or not self.overlap:
-                self._launch(i)
-            self._pending[i] = 0
-        for w in self._work:
-            w.wait()
-        self._work = []
-        if self._stream is not None:
-            torch.cuda.current_stream().wait_stream(self._stream)
+        """After backward(): reduce whatever has not been launched yet (buckets holding parameters that received no
+        gradient, or everything when overlap is off), wait, and drain the GEMM-order arena into the gradient arena.
+        The 1/world average is folded into the Adam kernel's grad_scale."""
+        if self.dp:
+            if self.sink:
+                if self.gemm is not None and any(s.written for s in self._slot_list):
+                    if self._layout_dirty:
+                        self._freeze_layout()
+                    overlapped = self.overlap and not self._recording
+                    for i, left in enumerate(self._gpending):        # buckets slot_written has not launched (0 = launched)
+                        if left > 0 or not overlapped:
+                            lo, hi, _ = self._gbuckets[i]
+                            self._all_reduce(self.gemm[lo:hi])
+                seen = set()
+                for p in self._leftover:
+                    if id(p) not in seen:
+                        seen.add(id(p))
+                        a, b = self._span_of[id(p)]
+                        self._all_reduce(self.flat_grad[a:b])
+                self._leftover = []
+            else:
+                for i, left in enumerate(self._pending):
+                    if left > 0 or not self.overlap:
+                        self._launch(i)
+                    self._pending[i] = 0
+            for w in self._work:
+                w.wait()
+            self._work = []
+            if self._stream is not None:
+                torch.cuda.current_stream().wait_stream(self._stream)
+        self.drain_grads()
 
     # ---- update -------------------------------------------------------------------------
     def step(self):

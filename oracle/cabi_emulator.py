@@ -82,11 +82,11 @@ class EmulatorBackend:
 
     # -- bookkeeping ---------------------------------------------------------
     def mg_abi_version(self):
-        return 1
+        return 2
 
     def mg_sizeof_desc(self, which):
         from michigan_amd import _cabi
-        return ctypes.sizeof(_cabi.ConvDesc if which == 0 else _cabi.WgradDesc)
+        return ctypes.sizeof((_cabi.ConvDesc, _cabi.WgradDesc, _cabi.GradSlot)[which])
 
     def mg_last_error(self):
         return b""
@@ -351,6 +351,39 @@ class EmulatorBackend:
         r = self._gemm_rows(cout, two)
         for which, p in enumerate((d0, d1) if two else (d0,)):
             _view(p, (cout, cin, taps), torch.float32)[:] = src[:, r + 32 * which, :cin].permute(1, 2, 0)
+        return 0
+
+    def mg_grad_slot_blocks(self, cout, cin, ntens):
+        return ntens * ((cin + 63) // 64) * ((cout + 3) // 4) + 1
+
+    def mg_grad_drain(self, table, nslots, block_slot, nblocks, has_sn, stream=None):
+        """Contract of include/michigan_hip.h `mg_grad_drain`, slot by slot (float64 arithmetic, one rounding)."""
+        from michigan_amd import _cabi
+        slots = (_cabi.GradSlot * nslots).from_address(_addr(table))
+        for sl in slots:
+            two = bool(sl.dst1)
+            shape = (sl.taps, sl.cols, sl.rows) if sl.swapped else (sl.taps, sl.rows, sl.cols)
+            g = _view(sl.gemm, shape, torch.float32)
+            gg = g.permute(0, 2, 1) if sl.swapped else g                      # [t, row, ci]
+            r = self._gemm_rows(sl.cout, two)
+            for which, dst in enumerate((sl.dst0, sl.dst1) if two else (sl.dst0,)):
+                val = gg[:, r + 32 * which, :sl.cin].permute(1, 2, 0).double()       # [co, ci, t]
+                if sl.w_sn:
+                    w_sn = _view(sl.w_sn, (sl.cout, sl.cin, sl.taps), torch.float32).double()
+                    u = _view(sl.u, (sl.cout,), torch.float32).double()
+                    v = _view(sl.v, (sl.cin * sl.taps,), torch.float32).double().view(sl.cin, sl.taps)
+                    sigma = float(_view(sl.sigma, (1,), torch.float32)[0])
+                    sdot = (val * w_sn).sum()
+                    val = (val - sdot * u[:, None, None] * v[None]) / sigma
+                d = _view(dst, (sl.cout, sl.cin, sl.taps), torch.float32)
+                d += val.float()
+            if sl.dbias_gemm:
+                nrows = int(r.max()) + 33 if two else sl.cout
+                db = _view(sl.dbias_gemm, (nrows,), torch.float32)
+                for which, dst in enumerate((sl.dbias0, sl.dbias1) if two else (sl.dbias0,)):
+                    _view(dst, (sl.cout,), torch.float32)[:] += db[r + 32 * which]
+                db.zero_()
+            g.zero_()
         return 0
 
     def mg_l1_mean_fwd(self, a, b, dtype, numel, out, partial, stream=None):
