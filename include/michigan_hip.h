@@ -221,6 +221,33 @@ int mg_unpack_wgrad(const float* dw, float* d0, float* d1, int32_t cout, int32_t
 int mg_l1_mean_fwd(const void* a, const void* b, int32_t dtype, int64_t numel, float* out, float* partial, void* stream);
 int mg_l1_mean_bwd(const void* a, const void* b, const float* gscale, int32_t dtype, int64_t numel, void* da, void* stream);
 
+/* Batched weight preparation (one launch for any number of images; tables live in device memory).
+ * mg_pack_job: mode 0 / 1 = mg_pack_weight's forward / data-gradient GEMM image of (w0[, w1]) in `dtype`, every element divided
+ *   by sigma[0] first when sigma != NULL (spectral norm); mode 2 = plain fp32 copy dst[i] = w0[i] / sigma[0] in the reference
+ *   layout (the W_sn tensor itself).  first_block = running sum of mg_pack_job_blocks(destination elements) over the preceding
+ *   jobs; block_job[b] = job that owns workgroup b. */
+typedef struct mg_pack_job {
+    const float* w0; const float* w1; void* dst; const float* sigma;
+    int32_t dtype, cout, cin, taps, rows_p, cols_p, mode, pad_;
+    int64_t first_block;
+} mg_pack_job;
+int     mg_pack_weights(const mg_pack_job* jobs_dev, int32_t njobs, const int32_t* block_job_dev, int32_t nblocks, void* stream);
+int64_t mg_pack_job_blocks(int64_t dst_elems);
+
+/* torch.nn.utils.spectral_norm's power iteration (dim 0, one iteration, spectral_norm.py: v <- normalize(W^T u, eps),
+ * u <- normalize(W v, eps), sigma = u . (W v)) for all layers of the table in four launches; do_power_iteration = 0 only evaluates
+ * sigma = u . (W v) with the stored vectors (eval mode).  w: [rows][cols] fp32; u [rows], v [cols] are updated in place (and
+ * copied to u_copy / v_copy when given: the values this forward's backward needs); scratch per layer: t1 [cols], t2 [rows],
+ * partial [mg_sn_layer_blocks(rows, cols, 2)][cols].  first_block_k1 / _k3 = running sums of mg_sn_layer_blocks(rows, cols, 0 / 1). */
+typedef struct mg_sn_layer {
+    const float* w; float* u; float* v; float* u_copy; float* v_copy; float* sigma;
+    float* t1; float* t2; float* partial;
+    int32_t rows, cols, first_block_k1, first_block_k3;
+} mg_sn_layer;
+int     mg_sn_power_iteration(const mg_sn_layer* layers_dev, int32_t nlayers, const int32_t* block_layer_k1, int32_t nblocks_k1,
+                              const int32_t* block_layer_k3, int32_t nblocks_k3, int32_t do_power_iteration, float eps, void* stream);
+int64_t mg_sn_layer_blocks(int32_t rows, int32_t cols, int32_t which);
+
 /* Batched drain of GEMM-order weight gradients into reference-layout gradients (one call per optimiser step instead of a
  * fill + unpack + spectral-norm backward + accumulate chain per convolution).  mg_conv_wgrad ACCUMULATES (fp32 atomics) into
  * `gemm` / `dbias_gemm`, which therefore may live in a persistent arena; this call adds every slot's gradient to its

@@ -55,6 +55,20 @@ class GradSlot(ctypes.Structure):
     ]
 
 
+class PackJob(ctypes.Structure):
+    """struct mg_pack_job (include/michigan_hip.h)."""
+    _fields_ = [("w0", _vp), ("w1", _vp), ("dst", _vp), ("sigma", _vp),
+                ("dtype", _i32), ("cout", _i32), ("cin", _i32), ("taps", _i32), ("rows_p", _i32), ("cols_p", _i32),
+                ("mode", _i32), ("pad_", _i32), ("first_block", _i64)]
+
+
+class SnLayer(ctypes.Structure):
+    """struct mg_sn_layer (include/michigan_hip.h)."""
+    _fields_ = [("w", _vp), ("u", _vp), ("v", _vp), ("u_copy", _vp), ("v_copy", _vp), ("sigma", _vp),
+                ("t1", _vp), ("t2", _vp), ("partial", _vp),
+                ("rows", _i32), ("cols", _i32), ("first_block_k1", _i32), ("first_block_k3", _i32)]
+
+
 # name -> (argtypes, restype); descriptors are passed by reference.
 _PROTOS = {
     "mg_conv_taps": ([ctypes.POINTER(ConvDesc), _vp], _i32),
@@ -80,6 +94,10 @@ _PROTOS = {
     "mg_unpack_wgrad": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_l1_mean_fwd": ([_vp, _vp, _i32, _i64, _vp, _vp, _vp], _i32),
     "mg_l1_mean_bwd": ([_vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
+    "mg_pack_weights": ([_vp, _i32, _vp, _i32, _vp], _i32),
+    "mg_pack_job_blocks": ([_i64], _i64),
+    "mg_sn_power_iteration": ([_vp, _i32, _vp, _i32, _vp, _i32, _i32, _f32, _vp], _i32),
+    "mg_sn_layer_blocks": ([_i32, _i32, _i32], _i64),
     "mg_grad_drain": ([_vp, _i32, _vp, _i32, _i32, _vp], _i32),
     "mg_grad_slot_blocks": ([_i32, _i32, _i32], _i64),
     "mg_wide_edge_weight": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp], _i32),
@@ -111,7 +129,7 @@ _PROTOS = {
     "mg_last_error": ([], ctypes.c_char_p),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
-_NO_STATUS = {"mg_grad_slot_blocks", "mg_stats_workspace", "mg_sizeof_desc", "mg_abi_version", "mg_last_error", "mg_noise_field_len", "mg_bicubic_ksize"}
+_NO_STATUS = {"mg_grad_slot_blocks", "mg_pack_job_blocks", "mg_sn_layer_blocks", "mg_stats_workspace", "mg_sizeof_desc", "mg_abi_version", "mg_last_error", "mg_noise_field_len", "mg_bicubic_ksize"}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmichigan_hip.so")
 
@@ -142,8 +160,9 @@ class HipBackend:
         if self._lib.mg_abi_version() != MG_ABI_VERSION:
             raise RuntimeError("libmichigan_hip.so ABI version mismatch")
         if (self._lib.mg_sizeof_desc(0) != ctypes.sizeof(ConvDesc) or self._lib.mg_sizeof_desc(1) != ctypes.sizeof(WgradDesc)
-                or self._lib.mg_sizeof_desc(2) != ctypes.sizeof(GradSlot)):
-            raise RuntimeError("ctypes mirror of mg_conv_desc / mg_wgrad_desc / mg_grad_slot is out of sync with the header")
+                or self._lib.mg_sizeof_desc(2) != ctypes.sizeof(GradSlot) or self._lib.mg_sizeof_desc(3) != ctypes.sizeof(PackJob)
+                or self._lib.mg_sizeof_desc(4) != ctypes.sizeof(SnLayer)):
+            raise RuntimeError("ctypes mirror of the descriptor structs is out of sync with include/michigan_hip.h")
 
     def __getattr__(self, fn):
         if fn not in _PROTOS:

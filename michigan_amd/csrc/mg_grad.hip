@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256) void grad_sn_dot_kernel(const mg_grad_slot* __
     if (tl.bias || !s.w_sn) return;
     const int T = s.taps, pitch = T | 1;
     const int ncol = min(64, s.cin - tl.ci0), run = ncol * T;
+    // element e of the contiguous run <-> (column c = e / T, tap t = e % T), walked without divisions in the loop
+    const int c0 = (int)threadIdx.x / T, t0 = (int)threadIdx.x - c0 * T, dc = 256 / T, dt = 256 - dc * T;
     double acc = 0.0;
     for (int k = 0; k < CO_PER && tl.co0 + k < s.cout; ++k) {
         const int co = tl.co0 + k;
@@ -78,7 +80,13 @@ __global__ __launch_bounds__(256) void grad_sn_dot_kernel(const mg_grad_slot* __
         load_tile<false>(s, 0, co, tl.ci0, lds, pitch);
         __syncthreads();
         const float* w = s.w_sn + ((size_t)co * s.cin + tl.ci0) * T;
-        for (int e = threadIdx.x; e < run; e += 256) acc += (double)lds[(e / T) * pitch + e % T] * (double)w[e];
+        float part = 0.f;                                        // <= ceil(64 * 49 / 256) = 13 products per thread and channel
+        for (int e = threadIdx.x, c = c0, t = t0; e < run; e += 256) {
+            part += lds[c * pitch + t] * w[e];
+            c += dc; t += dt;
+            if (t >= T) { t -= T; ++c; }
+        }
+        acc += (double)part;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
@@ -110,6 +118,7 @@ __global__ __launch_bounds__(256) void grad_drain_kernel(const mg_grad_slot* __r
     float sv = 0.f, inv_sigma = 1.f;
     if (sn) { sv = (float)*s.s; inv_sigma = 1.f / *s.sigma; }
     float* const dst = tl.which ? s.dst1 : s.dst0;
+    const int c0 = (int)threadIdx.x / T, t0 = (int)threadIdx.x - c0 * T, dc = 256 / T, dt = 256 - dc * T;
     for (int k = 0; k < CO_PER && tl.co0 + k < s.cout; ++k) {
         const int co = tl.co0 + k;
         __syncthreads();
@@ -118,10 +127,12 @@ __global__ __launch_bounds__(256) void grad_drain_kernel(const mg_grad_slot* __r
         float* d = dst + ((size_t)co * s.cin + tl.ci0) * T;
         const float su = sn ? sv * s.u[co] : 0.f;
         const float* vv = sn ? s.v + (size_t)tl.ci0 * T : nullptr;
-        for (int e = threadIdx.x; e < run; e += 256) {
-            float g = lds[(e / T) * pitch + e % T];
+        for (int e = threadIdx.x, c = c0, t = t0; e < run; e += 256) {
+            float g = lds[c * pitch + t];
             if (sn) g = (g - su * vv[e]) * inv_sigma;
             d[e] += g;
+            c += dc; t += dt;
+            if (t >= T) { t -= T; ++c; }
         }
     }
 }

@@ -1,0 +1,189 @@
+// mg_weights.hip -- batched weight preparation: every per-layer launch of the weight path folded into a few
+// network-wide ones.
+//
+//   mg_pack_weights         ONE launch that writes any number of GEMM images (mg_pack_weight's gather: permute + zero-pad
+//                           + cast + gamma|beta row interleave, optionally divided by a spectral-norm sigma) and plain
+//                           W / sigma copies; a job table in device memory says what goes where.  A training step issued
+//                           ~166 single-image pack launches of ~10 us (1.65 ms, profiles/r02a_kernel_stats.csv).
+//   mg_sn_power_iteration   torch.nn.utils.spectral_norm's power iteration (dim 0, one iteration) for ALL spectral-normed
+//                           layers of a network at once: v <- normalize(W^T u), u <- normalize(W v), sigma = u . (W v)
+//                           in four launches (two streaming passes over the weights + two tiny per-layer finishes)
+//                           instead of 2 rocBLAS gemv + 2 normalize launches per layer (architecture.py:39-42,
+//                           normalization.py:28-29: 18 layers in G, 6 in D, twice per training step each).
+// HBM-bound (weights only): K1 and K3 read every spectral-normed weight once each; no MFMA.
+#include "mg_common.h"
+
+namespace {
+
+constexpr int PACK_PER_BLOCK = 1024;      // destination elements per workgroup (4 per thread)
+constexpr int K1_ROWS = 32;               // rows of W per W^T u partial block
+constexpr int K3_ROWS = 4;                // rows of W per W v block (one wave each)
+
+__device__ __forceinline__ int row_to_co2(int r, int cout, bool two, int& which)
+{
+    if (!two) { which = 0; return r < cout ? r : -1; }
+    const int b = r >> 6, rem = r & 63;
+    which = rem >> 5;
+    const int co = b * 32 + (rem & 31);
+    return co < cout ? co : -1;
+}
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const mg_pack_job* __restrict__ jobs, const int32_t* __restrict__ block_job)
+{
+    const mg_pack_job& j = jobs[block_job[blockIdx.x]];
+    const int64_t base = ((int64_t)blockIdx.x - j.first_block) * PACK_PER_BLOCK;
+    if (j.mode == 2) {                                           // fp32 copy of w0 / sigma, reference layout
+        const int64_t total = (int64_t)j.cout * j.cin * j.taps;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t i = base + k * 256 + threadIdx.x;
+            if (i < total) reinterpret_cast<float*>(j.dst)[i] = j.sigma ? j.w0[i] / j.sigma[0] : j.w0[i];     // a true division, like torch
+        }
+        return;
+    }
+    const bool two = j.w1 != nullptr;
+    const int64_t total = (int64_t)j.taps * j.rows_p * j.cols_p;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        if (i >= total) continue;
+        const int c = (int)(i % j.cols_p);
+        const int r = (int)((i / j.cols_p) % j.rows_p);
+        const int t = (int)(i / ((int64_t)j.cols_p * j.rows_p));
+        int which = 0;
+        const int g = j.mode == 0 ? r : c, ci = j.mode == 0 ? c : r;
+        const int co = row_to_co2(g, j.cout, two, which);
+        float v = 0.f;
+        if (co >= 0 && ci < j.cin) v = (which ? j.w1 : j.w0)[((size_t)co * j.cin + ci) * j.taps + t];
+        if (j.sigma) v = v / j.sigma[0];
+        if (j.dtype == MG_BF16) reinterpret_cast<uint16_t*>(j.dst)[i] = f2bf(v);
+        else reinterpret_cast<float*>(j.dst)[i] = v;
+    }
+}
+
+// ---- spectral-norm power iteration ---------------------------------------------------------------------------------------
+// K1: partial[chunk][c] = sum over the chunk's K1_ROWS rows of W[r][c] * u[r]   (block = 256 columns x one row chunk)
+__global__ __launch_bounds__(256) void sn_wtu_kernel(const mg_sn_layer* __restrict__ layers, const int32_t* __restrict__ block_layer)
+{
+    const mg_sn_layer& L = layers[block_layer[blockIdx.x]];
+    const int rel = blockIdx.x - L.first_block_k1;
+    const int cblocks = (L.cols + 255) >> 8;
+    const int chunk = rel / cblocks, c = (rel % cblocks) * 256 + threadIdx.x;
+    if (c >= L.cols) return;
+    const int r0 = chunk * K1_ROWS, r1 = min(r0 + K1_ROWS, L.rows);
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) acc += L.w[(size_t)r * L.cols + c] * L.u[r];
+    L.partial[(size_t)chunk * L.cols + c] = acc;
+}
+
+__device__ __forceinline__ float block_sum1024(float v, float* red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < 16; ++i) t += red[i];
+    return t;
+}
+
+// K2: t1 = sum of the partials (fixed order), v = t1 / max(||t1||, eps)  (one 1024-thread block per layer)
+__global__ __launch_bounds__(1024) void sn_finish_v_kernel(const mg_sn_layer* __restrict__ layers, float eps)
+{
+    __shared__ float red[16];
+    const mg_sn_layer& L = layers[blockIdx.x];
+    const int chunks = (L.rows + K1_ROWS - 1) / K1_ROWS;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < L.cols; c += 1024) {
+        float t = 0.f;
+        for (int k = 0; k < chunks; ++k) t += L.partial[(size_t)k * L.cols + c];
+        L.t1[c] = t;
+        ss += t * t;
+    }
+    ss = block_sum1024(ss, red);
+    const float denom = fmaxf(sqrtf(ss), eps);
+    for (int c = threadIdx.x; c < L.cols; c += 1024) {
+        const float q = L.t1[c] / denom;
+        L.v[c] = q;
+        if (L.v_copy) L.v_copy[c] = q;
+    }
+}
+
+// K3: t2[r] = W[r] . v   (one wave per row)
+__global__ __launch_bounds__(256) void sn_wv_kernel(const mg_sn_layer* __restrict__ layers, const int32_t* __restrict__ block_layer)
+{
+    const mg_sn_layer& L = layers[block_layer[blockIdx.x]];
+    const int r = (blockIdx.x - L.first_block_k3) * K3_ROWS + (threadIdx.x >> 6);
+    if (r >= L.rows) return;
+    const float* __restrict__ w = L.w + (size_t)r * L.cols;
+    float acc = 0.f;
+    for (int c = threadIdx.x & 63; c < L.cols; c += 64) acc += w[c] * L.v[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) L.t2[r] = acc;
+}
+
+// K4: power iteration: u = t2 / max(||t2||, eps), sigma = u . t2; without it: sigma = u . t2 with the stored u
+__global__ __launch_bounds__(1024) void sn_finish_u_kernel(const mg_sn_layer* __restrict__ layers, float eps, int power_iteration)
+{
+    __shared__ float red[16];
+    const mg_sn_layer& L = layers[blockIdx.x];
+    float dot = 0.f;
+    if (power_iteration) {
+        float ss = 0.f;
+        for (int r = threadIdx.x; r < L.rows; r += 1024) ss += L.t2[r] * L.t2[r];
+        ss = block_sum1024(ss, red);
+        const float denom = fmaxf(sqrtf(ss), eps);
+        for (int r = threadIdx.x; r < L.rows; r += 1024) {
+            const float q = L.t2[r] / denom;
+            L.u[r] = q;
+            if (L.u_copy) L.u_copy[r] = q;
+            dot += q * L.t2[r];
+        }
+    } else {
+        for (int r = threadIdx.x; r < L.rows; r += 1024) dot += L.u[r] * L.t2[r];
+    }
+    dot = block_sum1024(dot, red);
+    if (threadIdx.x == 0) L.sigma[0] = dot;
+}
+
+}  // namespace
+
+extern "C" int64_t mg_pack_job_blocks(int64_t dst_elems) { return dst_elems <= 0 ? -1 : (dst_elems + PACK_PER_BLOCK - 1) / PACK_PER_BLOCK; }
+
+extern "C" int mg_pack_weights(const mg_pack_job* jobs_dev, int32_t njobs, const int32_t* block_job_dev, int32_t nblocks, void* stream)
+{
+    MG_CHECK_ARG(jobs_dev && block_job_dev && njobs > 0 && nblocks > 0, "mg_pack_weights: bad arguments");
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)nblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs_dev, block_job_dev);
+    MG_CHECK_LAUNCH("mg_pack_weights");
+    return MG_OK;
+}
+
+extern "C" int64_t mg_sn_layer_blocks(int32_t rows, int32_t cols, int32_t which)
+{
+    if (rows <= 0 || cols <= 0) return -1;
+    if (which == 0) return (int64_t)((cols + 255) / 256) * ((rows + K1_ROWS - 1) / K1_ROWS);      // K1 workgroups
+    if (which == 1) return (rows + K3_ROWS - 1) / K3_ROWS;                                         // K3 workgroups
+    if (which == 2) return (rows + K1_ROWS - 1) / K1_ROWS;                                         // row chunks = rows of `partial`
+    return -1;
+}
+
+extern "C" int mg_sn_power_iteration(const mg_sn_layer* layers_dev, int32_t nlayers, const int32_t* block_layer_k1, int32_t nblocks_k1,
+                                     const int32_t* block_layer_k3, int32_t nblocks_k3, int32_t do_power_iteration, float eps, void* stream)
+{
+    MG_CHECK_ARG(layers_dev && nlayers > 0 && block_layer_k3 && nblocks_k3 > 0, "mg_sn_power_iteration: bad arguments");
+    MG_CHECK_ARG(!do_power_iteration || (block_layer_k1 && nblocks_k1 > 0), "mg_sn_power_iteration: missing K1 table");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (do_power_iteration) {
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3((unsigned)nblocks_k1), dim3(256), 0, st, layers_dev, block_layer_k1);
+        MG_CHECK_LAUNCH("mg_sn_power_iteration(W^T u)");
+        hipLaunchKernelGGL(sn_finish_v_kernel, dim3((unsigned)nlayers), dim3(1024), 0, st, layers_dev, eps);
+        MG_CHECK_LAUNCH("mg_sn_power_iteration(v)");
+    }
+    hipLaunchKernelGGL(sn_wv_kernel, dim3((unsigned)nblocks_k3), dim3(256), 0, st, layers_dev, block_layer_k3);
+    MG_CHECK_LAUNCH("mg_sn_power_iteration(W v)");
+    hipLaunchKernelGGL(sn_finish_u_kernel, dim3((unsigned)nlayers), dim3(1024), 0, st, layers_dev, eps, do_power_iteration);
+    MG_CHECK_LAUNCH("mg_sn_power_iteration(u, sigma)");
+    return MG_OK;
+}

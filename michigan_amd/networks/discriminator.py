@@ -5,6 +5,7 @@ import numpy as np
 import torch.nn as nn
 
 from .. import ops
+from . import spectral
 from .base_network import BaseNetwork
 from .layers import HipConv2d
 from .normalization import get_nonspade_norm_layer
@@ -80,6 +81,7 @@ class MultiscaleDiscriminator(BaseNetwork):
         return ops.avgpool3s2(x)
 
     def forward(self, input):
+        spectral.prepare(self)            # every spectral-normed conv of this pass: power iteration + W / sigma + GEMM images, batched
         x = ops.pad_channels(ops.to_nhwc(input, self.compute_dtype), 8)
         result = []
         for _, d in self.named_children():

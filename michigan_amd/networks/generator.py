@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops
+from . import spectral
 from .architecture import SPADEResnetBlock
 from .base_network import BaseNetwork
 from .encoder import BackgroundEncode2, ImageEncoder3
@@ -56,6 +57,7 @@ class SPADEBGenerator(BaseNetwork):
 
     def forward(self, input=None, z=None, orient_mask=None, image_ref=None, input_tag=None, noise=None,
                 image_tag=None):
+        spectral.prepare(self)            # every spectral-normed conv of this pass: power iteration + W / sigma + GEMM images, batched
         opt, dt = self.opt, self.compute_dtype
         input_tag = input_tag.float()
         hair = input_tag[:, 1:2]

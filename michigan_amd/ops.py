@@ -135,21 +135,110 @@ def pack_weight(w0: torch.Tensor, w1: Optional[torch.Tensor], dtype, rows_p: int
     updates the arena without touching the version counters.  So the discriminator (run in the G step and again, unchanged, in the D step), the VGG tower
     (three passes per step) and the in-painting net are packed once per weight state instead of once per launch.
     Tensors that are not parameters (per-forward spectral-norm products W / sigma) are never cached."""
+    pre = getattr(w0, "_mg_packed", None)               # images the batched spectral-norm path produced for this very tensor
+    if pre is not None:
+        hit = pre.get((dtype, rows_p, cols_p, mode))
+        if hit is not None:
+            return hit
+    origin = getattr(w0, "_mg_sn_origin", None)
+    if origin is not None:                              # remember what the consumer of a spectral-normed weight asks for:
+        geoms = getattr(origin, "_mg_pack_geom", None)  # the batched path (networks/spectral.py) prepares exactly these images
+        if geoms is None:
+            geoms = origin._mg_pack_geom = set()
+        geoms.add((dtype, rows_p, cols_p, mode))
     slot = None
     if isinstance(w0, torch.nn.Parameter) and (w1 is None or isinstance(w1, torch.nn.Parameter)):
         slot = (w0.data_ptr(), 0 if w1 is None else w1.data_ptr(), dtype, rows_p, cols_p, mode)
         state = (w0._version, 0 if w1 is None else w1._version, _arena_epoch(w0), 0 if w1 is None else _arena_epoch(w1))
         hit = _PACK_CACHE.get(slot)
         # identity through weak references: a freed parameter's address (and version 0) can be re-used by a new one
-        if hit is not None and hit[0] == state and hit[1]() is w0 and (w1 is None or hit[2]() is w1):
-            return hit[3]
+        if hit is not None and hit[1]() is w0 and (w1 is None or hit[2]() is w1):
+            if hit[0] == state:
+                return hit[3]
+            arena = getattr(w0, "_mg_arena", None)
+            if BATCHED_PACK and arena is not None and hit[0][:2] == state[:2] and (w1 is None or getattr(w1, "_mg_arena", None) is arena):
+                _repack_arena(arena)                    # the optimiser stepped: refresh every image of this arena in ONE launch
+                hit = _PACK_CACHE.get(slot)
+                if hit is not None and hit[0] == state:
+                    return hit[3]
     dst = _pack_weight(w0, w1, dtype, rows_p, cols_p, mode)
     if slot is not None:
         if len(_PACK_CACHE) > 4096:                                  # slots of parameters that no longer exist
             for k in [k for k, v in _PACK_CACHE.items() if v[1]() is None]:
                 del _PACK_CACHE[k]
         _PACK_CACHE[slot] = (state, weakref.ref(w0), None if w1 is None else weakref.ref(w1), dst)   # one image per slot: a stale one is replaced
+        arena = getattr(w0, "_mg_arena", None)
+        if arena is not None:
+            _ARENA_PACK_TABLES.pop(id(arena), None)                  # the arena's job table has to learn about this slot
     return dst
+
+
+BATCHED_PACK = True          # A/B switch: refresh all packed images of an optimiser arena with one mg_pack_weights launch
+_ARENA_PACK_TABLES = {}      # id(arena) -> (weakref(arena), slots, job table (device), block map (device), nblocks)
+
+
+class DeviceTable:
+    """A ctypes struct array that lives in pinned host memory and is mirrored to the device with one async copy."""
+
+    def __init__(self, struct, n: int, device):
+        self.n, self.struct = n, struct
+        nbytes = ctypes.sizeof(struct) * n
+        cuda = torch.device(device).type == "cuda"
+        self.host = torch.zeros(nbytes, dtype=torch.uint8, pin_memory=cuda)
+        self.dev = torch.empty(nbytes, dtype=torch.uint8, device=device) if cuda else self.host
+        self.rows = (struct * n).from_address(self.host.data_ptr())
+        self._event = None
+
+    def begin_update(self):
+        if self._event is not None:
+            self._event.synchronize()                   # the previous upload (enqueued a forward pass ago) has finished
+        return self.rows
+
+    def upload(self):
+        if self.dev is not self.host:
+            self.dev.copy_(self.host, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+        return ctypes.c_void_p(self.dev.data_ptr())
+
+
+def block_map(counts, device) -> torch.Tensor:
+    """int32 map workgroup -> table row for the batched kernels (row i owns counts[i] consecutive workgroups)."""
+    m = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts, dtype=torch.int64))
+    return m.to(device)
+
+
+def _repack_arena(arena):
+    """Re-pack every cached GEMM image whose source parameters live in `arena` with one batched launch (in place: the
+    images keep their addresses) and stamp them with the parameters' current state."""
+    ent = _ARENA_PACK_TABLES.get(id(arena))
+    if ent is None or ent[0]() is not arena:
+        slots = []
+        for key, (state, r0, r1, dst) in _PACK_CACHE.items():
+            w0, w1 = r0(), (r1() if r1 is not None else None)
+            if w0 is None or getattr(w0, "_mg_arena", None) is not arena or (r1 is not None and w1 is None):
+                continue
+            slots.append((key, w0, w1, dst))
+        if not slots:
+            return
+        be = C.backend()
+        counts = [int(be.mg_pack_job_blocks(dst.numel())) for _, _, _, dst in slots]
+        table = DeviceTable(C.PackJob, len(slots), slots[0][3].device)
+        first = 0
+        for row, (key, w0, w1, dst), nb in zip(table.begin_update(), slots, counts):
+            _, _, dtype, rows_p, cols_p, mode = key
+            row.w0, row.w1, row.dst, row.sigma = w0.data_ptr(), (w1.data_ptr() if w1 is not None else None), dst.data_ptr(), None
+            row.dtype = C.MG_BF16 if dtype == torch.bfloat16 else C.MG_F32
+            row.cout, row.cin, row.taps = w0.shape[0], w0.shape[1], w0.shape[2] * w0.shape[3]
+            row.rows_p, row.cols_p, row.mode, row.first_block = rows_p, cols_p, mode, first
+            first += nb
+        ent = (weakref.ref(arena), slots, table, block_map(counts, slots[0][3].device), first, table.upload())
+        _ARENA_PACK_TABLES[id(arena)] = ent
+    _, slots, table, bmap, nblocks, tab_ptr = ent
+    C.backend().mg_pack_weights(tab_ptr, len(slots), _p(bmap), nblocks, _stream(bmap))
+    for key, w0, w1, dst in slots:
+        state = (w0._version, 0 if w1 is None else w1._version, _arena_epoch(w0), 0 if w1 is None else _arena_epoch(w1))
+        _PACK_CACHE[key] = (state, weakref.ref(w0), None if w1 is None else weakref.ref(w1), dst)
 
 
 _PACK_CACHE = {}
@@ -1036,10 +1125,27 @@ def spectral_weight(weight: torch.Tensor, u: torch.Tensor, v: torch.Tensor, do_p
         # lets a consuming convolution route its weight gradient through the optimiser's gradient sink, which applies this
         # layer's sigma-backward in the batched drain (optim.FlatAdam.drain_grads) instead of _SpectralScaleFn.backward
         w_sn._mg_sn = (weight, w_sn.detach(), uc, vc, sigma)
+        w_sn._mg_sn_origin = weight
         return w_sn
     out = torch.empty_like(wm).view_as(weight)
     be.mg_sn_scale(_p(weight.detach().contiguous()), _p(sigma), _p(out), weight.numel(), _stream(weight))
+    out._mg_sn_origin = weight
     return out
+
+
+class _SpectralPrecomputedFn(torch.autograd.Function):
+    """_SpectralScaleFn for a W / sigma that the batched path (networks/spectral.py) has already computed: `holder[0]`."""
+
+    @staticmethod
+    def forward(ctx, weight, u, v, sigma, holder):
+        ctx.set_materialize_grads(False)
+        out = holder[0]
+        ctx.save_for_backward(out, u, v, sigma)
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _SpectralScaleFn.backward(ctx, g) + (None,)
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, *, lr, beta1, beta2, eps, step, grad_scale=1.0):

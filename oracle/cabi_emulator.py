@@ -86,7 +86,7 @@ class EmulatorBackend:
 
     def mg_sizeof_desc(self, which):
         from michigan_amd import _cabi
-        return ctypes.sizeof((_cabi.ConvDesc, _cabi.WgradDesc, _cabi.GradSlot)[which])
+        return ctypes.sizeof((_cabi.ConvDesc, _cabi.WgradDesc, _cabi.GradSlot, _cabi.PackJob, _cabi.SnLayer)[which])
 
     def mg_last_error(self):
         return b""
@@ -351,6 +351,51 @@ class EmulatorBackend:
         r = self._gemm_rows(cout, two)
         for which, p in enumerate((d0, d1) if two else (d0,)):
             _view(p, (cout, cin, taps), torch.float32)[:] = src[:, r + 32 * which, :cin].permute(1, 2, 0)
+        return 0
+
+    def mg_pack_job_blocks(self, n):
+        return (n + 1023) // 1024
+
+    def mg_pack_weights(self, jobs, njobs, block_job, nblocks, stream=None):
+        from michigan_amd import _cabi
+        for j in (_cabi.PackJob * njobs).from_address(_addr(jobs)):
+            sig = float(_view(j.sigma, (1,), torch.float32)[0]) if j.sigma else None
+            if j.mode == 2:
+                w = _view(j.w0, (j.cout * j.cin * j.taps,), torch.float32)
+                _view(j.dst, (j.cout * j.cin * j.taps,), torch.float32)[:] = w / sig if sig is not None else w
+                continue
+            srcs = []
+            for p in (j.w0, j.w1):
+                if p:
+                    w = _view(p, (j.cout, j.cin, j.taps), torch.float32)
+                    srcs.append((w / sig if sig is not None else w).contiguous())
+            self.mg_pack_weight(srcs[0].data_ptr(), srcs[1].data_ptr() if len(srcs) > 1 else None, j.dst, j.dtype, j.cout, j.cin,
+                                j.taps, j.rows_p, j.cols_p, j.mode)
+        return 0
+
+    def mg_sn_layer_blocks(self, rows, cols, which):
+        return ((cols + 255) // 256) * ((rows + 31) // 32) if which == 0 else ((rows + 3) // 4 if which == 1 else (rows + 31) // 32)
+
+    def mg_sn_power_iteration(self, layers, nlayers, bl1, nb1, bl3, nb3, do_power_iteration, eps, stream=None):
+        """torch/nn/utils/spectral_norm.py compute_weight (dim 0, one iteration), layer by layer, in float64."""
+        from michigan_amd import _cabi
+        for L in (_cabi.SnLayer * nlayers).from_address(_addr(layers)):
+            w = _view(L.w, (L.rows, L.cols), torch.float32).double()
+            u, v = _view(L.u, (L.rows,), torch.float32), _view(L.v, (L.cols,), torch.float32)
+            if do_power_iteration:
+                t1 = w.t() @ u.double()
+                vn = t1 / max(float(t1.norm()), eps)
+                v[:] = vn.float()
+                if L.v_copy:
+                    _view(L.v_copy, (L.cols,), torch.float32)[:] = vn.float()
+                t2 = w @ v.double()
+                un = t2 / max(float(t2.norm()), eps)
+                u[:] = un.float()
+                if L.u_copy:
+                    _view(L.u_copy, (L.rows,), torch.float32)[:] = un.float()
+            else:
+                t2 = w @ v.double()
+            _view(L.sigma, (1,), torch.float32)[0] = float(u.double() @ t2)
         return 0
 
     def mg_grad_slot_blocks(self, cout, cin, ntens):

@@ -122,3 +122,44 @@ def test_use_ig_orientation_channels_are_validated(emulator_backend):
     model = Pix2PixModel(opt)
     with pytest.raises(ValueError, match="orient"):
         model(synth_loader_batch(1, 64, seed=3), mode="inference")
+
+
+def test_batched_weight_paths_equal_per_layer_paths(emulator_backend):
+    """The network-wide launches (spectral-norm power iteration + W / sigma + GEMM images: networks/spectral.SpectralPlan;
+    arena re-pack: ops._repack_arena; gradient drain: optim.FlatAdam.drain_grads) against the per-layer paths they replace,
+    on the full trainer: same losses, weights and spectral-norm vectors after two iterations, and they really ran."""
+    from michigan_amd import _cabi, ops
+    from michigan_amd.model import Pix2PixTrainer
+    from michigan_amd.networks import spectral
+    cfg = TP.CFGS["A"]
+    be = _cabi.backend()
+    calls = {"mg_sn_power_iteration": 0, "mg_pack_weights": 0, "mg_grad_drain": 0, "mg_sn_normalize": 0, "mg_unpack_wgrad": 0}
+    for name in calls:
+        orig = getattr(be, name)
+        setattr(be, name, (lambda o, n: (lambda *a, **k: (calls.__setitem__(n, calls[n] + 1), o(*a, **k))[1]))(orig, name))
+    recs, counts = [], []
+    for flag in (True, False):
+        saved = (spectral.BATCHED, ops.BATCHED_PACK, ops.GRAD_SINK)
+        spectral.BATCHED = ops.BATCHED_PACK = ops.GRAD_SINK = flag
+        for k in calls:
+            calls[k] = 0
+        try:
+            torch.manual_seed(0)
+            trainer = Pix2PixTrainer(TP.repo_options(cfg))
+            TP.load_weights(trainer, cfg)
+            recs.append(TP.drive(trainer, cfg))
+            counts.append(dict(calls))
+        finally:
+            spectral.BATCHED, ops.BATCHED_PACK, ops.GRAD_SINK = saved
+    on, off = counts
+    assert on["mg_sn_power_iteration"] >= 5 and on["mg_pack_weights"] >= 6 and on["mg_grad_drain"] == 4
+    assert off["mg_sn_power_iteration"] == off["mg_pack_weights"] == off["mg_grad_drain"] == 0
+    assert on["mg_sn_normalize"] < off["mg_sn_normalize"] / 3 and on["mg_unpack_wgrad"] < off["mg_unpack_wgrad"] / 5
+    for k in recs[0]:
+        a, b = recs[0][k], recs[1][k]
+        if ".loss." in k:
+            assert abs(float(a) - float(b)) < 1e-4 * max(abs(float(b)), 0.1), k
+        elif "weight_u" in k or "weight_v" in k or "running" in k:
+            assert np.abs(a - b).max() < 1e-4 * np.abs(b).max(), k
+        elif k.startswith(("G.", "D.")):
+            assert (np.abs(a - b) > 2 * 4e-4 * 2 + 1e-5).mean() < 0.005, k

@@ -111,7 +111,7 @@ def test_generator_fullwidth_gradients_match_oracle_autograd(hip_backend):
     256x256, batch 2, on the HIP kernels and is compared with torch autograd through the oracle restatement on the
     host for parameters of every kind the wide layers have (spectral-normed 3x3 at 1024 and 512 channels, a 1x1
     shortcut, gamma / beta convs, the partial-conv encoder's 1024-channel layer, a bias).
-    Tolerance: 5e-3 of each tensor's largest gradient element (fp32 MFMA accumulation order vs oneDNN's)."""
+    Tolerance: 5e-3 of each tensor's largest gradient element against the oracle run in float64 (see below)."""
     from michigan_amd import networks
     from michigan_amd.model import default_options
     from michigan_amd.synth import synth_batch, synth_state_dict
@@ -131,17 +131,28 @@ def test_generator_fullwidth_gradients_match_oracle_autograd(hip_backend):
     (out.float() * gy.cuda()).sum().backward()
     got = {n: p.grad.detach().float().cpu() for n, p in G.named_parameters() if n in names}
     assert sorted(got) == sorted(names)
-    osd = {k: (v.clone().requires_grad_() if k in names else v.clone()) for k, v in sd.items()}
     torch.set_num_threads(min(32, torch.get_num_threads()))
-    ref_out = O.spadeb_generator(osd, opt, b["input_ref"], b["orient"], b["image_ref"], b["input_tag"], b["noise"], b["image_tag"], True, {})
-    (ref_out * gy).sum().backward()
-    assert (out.detach().float().cpu() - ref_out.detach()).abs().max().item() < 1e-3
-    worst = {}
-    for n in names:
-        want = osd[n].grad
-        worst[n] = ((got[n] - want).abs().max() / want.abs().max()).item()
-    print("full-width gradient errors (relative to each tensor's max):", {k: "%.1e" % v for k, v in worst.items()})
-    assert max(worst.values()) < 5e-3, worst
+
+    def oracle_grads(dt):
+        osd = {k: (v.to(dt).clone().requires_grad_() if k in names else (v.to(dt) if v.is_floating_point() else v.clone()))
+               for k, v in sd.items()}
+        bb = {k: v.to(dt) for k, v in b.items()}
+        ref_out = O.spadeb_generator(osd, opt, bb["input_ref"], bb["orient"], bb["image_ref"], bb["input_tag"], bb["noise"],
+                                     bb["image_tag"], True, {})
+        (ref_out * gy.to(dt)).sum().backward()
+        return ref_out.detach(), {n: osd[n].grad.double() for n in names}
+    # The fp64 run of the oracle is the yardstick; its own fp32 run measures how well-conditioned each gradient is (batch
+    # statistics over 2 x 4 x 4 latents and the spectral-norm term sum(g * W_sn) cancel heavily: the fp32 ATen run is up to
+    # 3e-2 away from fp64 on G_middle_1.conv_1).  The HIP fp32 kernels must be within 5e-3 of fp64, or within twice the
+    # fp32 CPU run's own distance where that is larger.
+    out64, ref64 = oracle_grads(torch.float64)
+    _, ref32 = oracle_grads(torch.float32)
+    assert (out.detach().double().cpu() - out64).abs().max().item() < 1e-3
+    rel = lambda a, c: ((a.double() - c).abs().max() / c.abs().max()).item()
+    worst, cond = {n: rel(got[n], ref64[n]) for n in names}, {n: rel(ref32[n], ref64[n]) for n in names}
+    print("full-width gradient errors vs fp64 oracle (HIP fp32 | ATen fp32):", {n: "%.1e | %.1e" % (worst[n], cond[n]) for n in names})
+    bad = {n: (worst[n], cond[n]) for n in names if worst[n] > max(5e-3, 2 * cond[n])}
+    assert not bad, bad
 
 
 def test_generator_bf16_default_init_matches_oracle_tightly(hip_backend):

@@ -721,3 +721,72 @@ def test_gradient_sink_drain_matches_autograd_path(dt):
     _close(f"sink {dt}: hip vs emulator", hip_s[0], emu_s[0], tol)
     _close(f"sink {dt}: sink vs autograd path (hip)", hip_s[0], hip_a[0], 2e-4 if dt == "f32" else 2.0 ** -7)
     _close(f"sink {dt}: sink vs autograd path (emulator)", emu_s[0], emu_a[0], 1e-5)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_batched_spectral_norm_and_pack_match_contract(dt):
+    """mg_sn_power_iteration + mg_pack_weights (network-wide spectral norm / GEMM-image launches) and the arena re-pack on the
+    HIP kernels vs the contract emulator: three optimiser iterations of a small net with two spectral-normed convs (3x3 with
+    bias, 1x1 without), a SPADE pair and plain 7x7 / 4x4-s2 convs; from the second iteration on the batched paths are live."""
+    import torch.nn as nn
+    from michigan_amd import ops
+    from michigan_amd.networks import spectral
+    from michigan_amd.networks.layers import HipConv2d
+    from michigan_amd.networks.normalization import SPADE
+    from michigan_amd.optim import FlatAdam
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c7 = HipConv2d(8, 24, 7, padding=3)
+            self.c3 = spectral.spectral_norm(HipConv2d(24, 40, 3, padding=1))
+            self.c1 = spectral.spectral_norm(HipConv2d(40, 72, 1, bias=False))
+            self.sp = SPADE("spadesyncbatch3x3", 72, 4)
+            self.c4 = HipConv2d(72, 16, 4, stride=2, padding=2)
+
+        def forward(self, x, seg):
+            spectral.prepare(self)
+            h = self.c7(x, act=ops.ACT_LRELU)
+            h = self.c3(h, act=ops.ACT_RELU)
+            h = self.c1(h)
+            h = self.sp(h, seg, act=ops.ACT_LRELU)
+            return self.c4(h)
+
+    torch.manual_seed(6)
+    sd = {k: v.clone() for k, v in Net().state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 20, 28, 8, generator=g).to(DT[dt])
+    seg = (torch.rand(2, 4, 20, 28, generator=g) > 0.5).float()
+    gy = torch.randn(2, 11, 15, 16, generator=g).to(DT[dt])
+
+    def fn(x, seg, gy):
+        from michigan_amd import _cabi
+        be = _cabi.backend()
+        n = {"sn": 0, "pack": 0}
+        o1, o2 = be.mg_sn_power_iteration, be.mg_pack_weights
+        be.mg_sn_power_iteration = lambda *a: (n.__setitem__("sn", n["sn"] + 1), o1(*a))[1]
+        be.mg_pack_weights = lambda *a: (n.__setitem__("pack", n["pack"] + 1), o2(*a))[1]
+        try:
+            net = Net().to(x.device)
+            net.load_state_dict(sd)
+            opt = FlatAdam(net.parameters(), lr=1e-3)
+            outs = []
+            for it in range(3):
+                opt.zero_grad()
+                out = net(x, seg)
+                (out.float() * gy.float()).sum().backward()
+                opt.step()
+                outs.append(out.detach().float().clone())
+            with torch.no_grad():
+                net.eval()
+                outs.append(net(x, seg).float().clone())          # eval mode: sigma from the stored u, v
+            assert n["sn"] >= 3 and n["pack"] >= 4, n
+            return outs + [net.c3.weight_u.clone(), net.c1.weight_v.clone(), opt.flat.clone()]
+        finally:
+            be.mg_sn_power_iteration, be.mg_pack_weights = o1, o2
+    (hip, _), (ref, _) = _both(fn, (x, seg, gy))
+    for i in range(4):
+        _close(f"batched weights {dt}: output of pass {i}", hip[i], ref[i], 5e-4 if dt == "f32" else 2.0 ** -5)
+    _close(f"batched weights {dt}: u", hip[4], ref[4], 1e-4)
+    _close(f"batched weights {dt}: v", hip[5], ref[5], 1e-4)
+    assert ((hip[6].cpu() - ref[6]).abs() > 2.5e-3).float().mean() < 0.01       # Adam (lr 1e-3): sign-like updates, see trainer_parity.compare
