@@ -224,7 +224,7 @@ int mg_l1_mean_bwd(const void* a, const void* b, const float* gscale, int32_t dt
 /* Batched weight preparation (one launch for any number of images; tables live in device memory).
  * mg_pack_job: mode 0 / 1 = mg_pack_weight's forward / data-gradient GEMM image of (w0[, w1]) in `dtype`, every element divided
  *   by sigma[0] first when sigma != NULL (spectral norm); mode 2 = plain fp32 copy dst[i] = w0[i] / sigma[0] in the reference
- *   layout (the W_sn tensor itself).  first_block = running sum of mg_pack_job_blocks(destination elements) over the preceding
+ *   layout (the W_sn tensor itself).  first_block = running sum of mg_pack_job_blocks(...) over the preceding
  *   jobs; block_job[b] = job that owns workgroup b. */
 typedef struct mg_pack_job {
     const float* w0; const float* w1; void* dst; const float* sigma;
@@ -232,7 +232,7 @@ typedef struct mg_pack_job {
     int64_t first_block;
 } mg_pack_job;
 int     mg_pack_weights(const mg_pack_job* jobs_dev, int32_t njobs, const int32_t* block_job_dev, int32_t nblocks, void* stream);
-int64_t mg_pack_job_blocks(int64_t dst_elems);
+int64_t mg_pack_job_blocks(int32_t mode, int32_t cout, int32_t cin, int32_t taps, int32_t rows_p, int32_t cols_p);   /* workgroups of one job; -1 = not batchable (taps > 49) */
 
 /* torch.nn.utils.spectral_norm's power iteration (dim 0, one iteration, spectral_norm.py: v <- normalize(W^T u, eps),
  * u <- normalize(W v, eps), sigma = u . (W v)) for all layers of the table in four launches; do_power_iteration = 0 only evaluates

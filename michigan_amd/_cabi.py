@@ -95,7 +95,7 @@ _PROTOS = {
     "mg_l1_mean_fwd": ([_vp, _vp, _i32, _i64, _vp, _vp, _vp], _i32),
     "mg_l1_mean_bwd": ([_vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
     "mg_pack_weights": ([_vp, _i32, _vp, _i32, _vp], _i32),
-    "mg_pack_job_blocks": ([_i64], _i64),
+    "mg_pack_job_blocks": ([_i32, _i32, _i32, _i32, _i32, _i32], _i64),
     "mg_sn_power_iteration": ([_vp, _i32, _vp, _i32, _vp, _i32, _i32, _f32, _vp], _i32),
     "mg_sn_layer_blocks": ([_i32, _i32, _i32], _i64),
     "mg_grad_drain": ([_vp, _i32, _vp, _i32, _i32, _vp], _i32),

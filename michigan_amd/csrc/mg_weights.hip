@@ -28,36 +28,76 @@ __device__ __forceinline__ int row_to_co2(int r, int cout, bool two, int& which)
     return co < cout ? co : -1;
 }
 
+// Tile = 4 destination rows x 64 destination columns x all T taps.  Destination element (t, r, c) of a GEMM image comes from
+//   mode 0: W[co(r)][ci = c][t]      mode 1: W[co(c)][ci = r][t]       (co() = identity, or the gamma|beta row interleave)
+// The reference layout has t fastest, so a gather by destination index (what the per-image pack_kernel does) touches every
+// 64-byte line of W once per tap, T blocks apart: with 438 MB of generator weights that is T re-reads from HBM (the first batched
+// version measured 1.5 TB/s of useful bytes).  Here a workgroup reads its sources as contiguous runs (mode 0: 64*T floats per row,
+// mode 1: 4*T floats per column), transposes through LDS (pitch T|1: conflict-free for T = 1, 9, 16, 49) and writes
+// 128-byte destination rows: every byte of W is read once.
+constexpr int PK_ROWS = 4, PK_COLS = 64, PK_MAXT = 49;
+
 __global__ __launch_bounds__(256) void pack_weights_kernel(const mg_pack_job* __restrict__ jobs, const int32_t* __restrict__ block_job)
 {
+    __shared__ float tile[PK_ROWS * PK_COLS * (PK_MAXT + 1)];
     const mg_pack_job& j = jobs[block_job[blockIdx.x]];
-    const int64_t base = ((int64_t)blockIdx.x - j.first_block) * PACK_PER_BLOCK;
+    const int rel = (int)((int64_t)blockIdx.x - j.first_block);
+    const int tid = threadIdx.x;
     if (j.mode == 2) {                                           // fp32 copy of w0 / sigma, reference layout
-        const int64_t total = (int64_t)j.cout * j.cin * j.taps;
+        const int64_t total = (int64_t)j.cout * j.cin * j.taps, base = (int64_t)rel * PACK_PER_BLOCK;
+        const float sg = j.sigma ? j.sigma[0] : 1.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t i = base + k * 256 + threadIdx.x;
-            if (i < total) reinterpret_cast<float*>(j.dst)[i] = j.sigma ? j.w0[i] / j.sigma[0] : j.w0[i];     // a true division, like torch
+            const int64_t i = base + k * 256 + tid;
+            if (i < total) reinterpret_cast<float*>(j.dst)[i] = j.sigma ? j.w0[i] / sg : j.w0[i];     // a true division, like torch
         }
         return;
     }
     const bool two = j.w1 != nullptr;
-    const int64_t total = (int64_t)j.taps * j.rows_p * j.cols_p;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int64_t i = base + k * 256 + threadIdx.x;
-        if (i >= total) continue;
-        const int c = (int)(i % j.cols_p);
-        const int r = (int)((i / j.cols_p) % j.rows_p);
-        const int t = (int)(i / ((int64_t)j.cols_p * j.rows_p));
-        int which = 0;
-        const int g = j.mode == 0 ? r : c, ci = j.mode == 0 ? c : r;
-        const int co = row_to_co2(g, j.cout, two, which);
-        float v = 0.f;
-        if (co >= 0 && ci < j.cin) v = (which ? j.w1 : j.w0)[((size_t)co * j.cin + ci) * j.taps + t];
-        if (j.sigma) v = v / j.sigma[0];
-        if (j.dtype == MG_BF16) reinterpret_cast<uint16_t*>(j.dst)[i] = f2bf(v);
-        else reinterpret_cast<float*>(j.dst)[i] = v;
+    const int T = j.taps, pitch = T | 1;
+    const int cblocks = (j.cols_p + PK_COLS - 1) / PK_COLS;
+    const int r0 = (rel / cblocks) * PK_ROWS, c0 = (rel % cblocks) * PK_COLS;
+    const float sg = j.sigma ? j.sigma[0] : 1.f;
+    // ---- load: contiguous runs of the reference-layout source ----------------------------------------------------------------
+    if (j.mode == 0) {
+        const int ncol = min(PK_COLS, j.cin - c0);               // source columns (ci) that exist; the rest of the tile is zero padding
+        for (int rr = 0; rr < PK_ROWS; ++rr) {
+            int which = 0;
+            const int co = (r0 + rr < j.rows_p) ? row_to_co2(r0 + rr, j.cout, two, which) : -1;
+            const float* src = (co >= 0 && ncol > 0) ? (which ? j.w1 : j.w0) + ((size_t)co * j.cin + c0) * T : nullptr;
+            const int run = src ? ncol * T : 0;
+            int c = tid / T, t = tid - c * T;
+            const int dc = 256 / T, dt = 256 - dc * T;
+            for (int e = tid; e < PK_COLS * T; e += 256) {
+                tile[(rr * PK_COLS + c) * pitch + t] = e < run ? src[e] : 0.f;
+                c += dc; t += dt;
+                if (t >= T) { t -= T; ++c; }
+            }
+        }
+    } else {
+        const int nrow = min(PK_ROWS, j.cin - r0);               // source rows (ci) that exist
+        const int per = PK_ROWS * T;                             // one column's contiguous run: W[co][r0 .. r0+3][0 .. T)
+        for (int e = tid; e < PK_COLS * per; e += 256) {
+            const int cc = e / per, rem = e - cc * per;
+            const int rr = rem / T, t = rem - rr * T;
+            int which = 0;
+            const int co = (c0 + cc < j.cols_p) ? row_to_co2(c0 + cc, j.cout, two, which) : -1;
+            float v = 0.f;
+            if (co >= 0 && rr < nrow) v = (which ? j.w1 : j.w0)[((size_t)co * j.cin + r0) * T + rem];
+            tile[(rr * PK_COLS + cc) * pitch + t] = v;
+        }
+    }
+    __syncthreads();
+    // ---- store: rows of 64 consecutive destination columns (2 per thread) ----------------------------------------------------------
+    const int rr = tid >> 6, cp = (tid & 31) * 2, th = (tid >> 5) & 1;          // 4 rows x 32 column pairs x 2 tap phases
+    const int r = r0 + rr, c = c0 + cp;
+    if (r >= j.rows_p || c >= j.cols_p) return;                                   // cols_p is even (a multiple of 8)
+    for (int t = th; t < T; t += 2) {
+        float v0 = tile[(rr * PK_COLS + cp) * pitch + t], v1 = tile[(rr * PK_COLS + cp + 1) * pitch + t];
+        if (j.sigma) { v0 = v0 / sg; v1 = v1 / sg; }
+        const size_t o = ((size_t)t * j.rows_p + r) * j.cols_p + c;
+        if (j.dtype == MG_BF16) reinterpret_cast<uint32_t*>(j.dst)[o >> 1] = f2bf2(v0, v1);
+        else { float2 p; p.x = v0; p.y = v1; *reinterpret_cast<float2*>(reinterpret_cast<float*>(j.dst) + o) = p; }
     }
 }
 
@@ -150,7 +190,12 @@ __global__ __launch_bounds__(1024) void sn_finish_u_kernel(const mg_sn_layer* __
 
 }  // namespace
 
-extern "C" int64_t mg_pack_job_blocks(int64_t dst_elems) { return dst_elems <= 0 ? -1 : (dst_elems + PACK_PER_BLOCK - 1) / PACK_PER_BLOCK; }
+extern "C" int64_t mg_pack_job_blocks(int32_t mode, int32_t cout, int32_t cin, int32_t taps, int32_t rows_p, int32_t cols_p)
+{
+    if (mode == 2) return cout > 0 && cin > 0 && taps > 0 ? ((int64_t)cout * cin * taps + PACK_PER_BLOCK - 1) / PACK_PER_BLOCK : -1;
+    if ((mode != 0 && mode != 1) || rows_p <= 0 || cols_p <= 0 || (cols_p & 1) || taps <= 0 || taps > PK_MAXT) return -1;
+    return (int64_t)((rows_p + PK_ROWS - 1) / PK_ROWS) * ((cols_p + PK_COLS - 1) / PK_COLS);
+}
 
 extern "C" int mg_pack_weights(const mg_pack_job* jobs_dev, int32_t njobs, const int32_t* block_job_dev, int32_t nblocks, void* stream)
 {

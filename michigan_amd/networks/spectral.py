@@ -91,7 +91,8 @@ class SpectralPlan:
         if not BATCHED or not self.entries:
             return False
         ws = [m.weight_orig for m, _ in self.entries]
-        if any(not h.fusable(w) or not w.is_cuda and C.backend().name == "hip" for (m, h), w in zip(self.entries, ws)):
+        if any(not h.fusable(w) or w.shape[2] * w.shape[3] > 49 or (not w.is_cuda and C.backend().name == "hip")
+               for (m, h), w in zip(self.entries, ws)):
             return False
         if any(not getattr(w, "_mg_pack_geom", None) for w in ws):
             return False                                     # first pass: the per-layer path records what the convolutions need
@@ -150,7 +151,9 @@ class SpectralPlan:
             counts = []
             for (i, g) in jobs:
                 w = ws[i]
-                counts.append(int(be.mg_pack_job_blocks(w.numel() if g is None else w.shape[2] * w.shape[3] * g[1] * g[2])))
+                taps = w.shape[2] * w.shape[3]
+                counts.append(int(be.mg_pack_job_blocks(2, w.shape[0], w.shape[1], taps, 0, 0) if g is None
+                                  else be.mg_pack_job_blocks(g[3], w.shape[0], w.shape[1], taps, g[1], g[2])))
             jt = st[("jobtable",) + key] = (ops.DeviceTable(C.PackJob, len(jobs), dev), counts, ops.block_map(counts, dev))
         table, counts, bmap = jt
         first = 0

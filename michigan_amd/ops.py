@@ -222,7 +222,11 @@ def _repack_arena(arena):
         if not slots:
             return
         be = C.backend()
-        counts = [int(be.mg_pack_job_blocks(dst.numel())) for _, _, _, dst in slots]
+        slots = [sl for sl in slots if sl[1].shape[2] * sl[1].shape[3] <= 49]
+        if not slots:
+            return
+        counts = [int(be.mg_pack_job_blocks(key[5], w0.shape[0], w0.shape[1], w0.shape[2] * w0.shape[3], key[3], key[4]))
+                  for key, w0, _, _ in slots]
         table = DeviceTable(C.PackJob, len(slots), slots[0][3].device)
         first = 0
         for row, (key, w0, w1, dst), nb in zip(table.begin_update(), slots, counts):

@@ -353,8 +353,10 @@ class EmulatorBackend:
             _view(p, (cout, cin, taps), torch.float32)[:] = src[:, r + 32 * which, :cin].permute(1, 2, 0)
         return 0
 
-    def mg_pack_job_blocks(self, n):
-        return (n + 1023) // 1024
+    def mg_pack_job_blocks(self, mode, cout, cin, taps, rows_p, cols_p):
+        if mode == 2:
+            return (cout * cin * taps + 1023) // 1024
+        return -1 if taps > 49 else ((rows_p + 3) // 4) * ((cols_p + 63) // 64)
 
     def mg_pack_weights(self, jobs, njobs, block_job, nblocks, stream=None):
         from michigan_amd import _cabi
