@@ -20,6 +20,7 @@ Reference call sites replaced (all ATen today):
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
@@ -36,7 +37,8 @@ WGRAD_USE_TR = True
 SYNC_BN_GROUP = None
 # Weight / bias gradients of convolutions whose parameters live in an optim.FlatAdam arena bypass autograd: the wgrad kernel
 # accumulates into the arena's persistent GEMM-order buffer and one batched launch per optimiser step drains it (optim.py).
-GRAD_SINK = True
+_LEGACY_WEIGHTS = os.environ.get("MG_LEGACY_WEIGHTS") == "1"      # A/B: per-layer pack / spectral norm / unpack paths (round-1 behaviour)
+GRAD_SINK = not _LEGACY_WEIGHTS
 STATS_FROM_UPSAMPLE_SOURCE = True     # batch statistics of a 2x-upsampled tensor from its quarter-size source (A/B: tools/ab_pyflag.py)
 
 
@@ -173,7 +175,7 @@ def pack_weight(w0: torch.Tensor, w1: Optional[torch.Tensor], dtype, rows_p: int
     return dst
 
 
-BATCHED_PACK = True          # A/B switch: refresh all packed images of an optimiser arena with one mg_pack_weights launch
+BATCHED_PACK = not _LEGACY_WEIGHTS          # A/B switch: refresh all packed images of an optimiser arena with one mg_pack_weights launch
 _ARENA_PACK_TABLES = {}      # id(arena) -> (weakref(arena), slots, job table (device), block map (device), nblocks)
 
 
