@@ -16,6 +16,7 @@
 // (exact fp32 fma chain) -- same tiling, same LDS image (64 B of K per row).
 
 int g_mg_conv_splitk = 1;        // deterministic split-K for low-resolution long-K layers (mg_set_option(5, v))
+int g_mg_conv_halo_ring = 4;     // weight-slab ring of the big halo tile: 3 = two taps in flight, 4 = three (mg_set_option(9, v))
 int g_mg_conv_halo_big = 1;      // 128 channels x 16x16 pixel halo tiles where the launch is big enough (mg_set_option(4, v))
 int g_mg_conv_halo = 1;          // 3x3 stride-1 convs on the LDS halo-tile kernel (mg_set_option(2, v))
 int g_mg_conv_bigtiles = 1;      // allow the 128x256 / 256x256 tiles (mg_set_option(1, v))
@@ -573,5 +574,6 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 6 && (value == 0 || value == 1)) { g_mg_conv_thin = value; return MG_OK; }
     if (key == 7 && (value == 0 || value == 1)) { g_mg_conv_wide = value; return MG_OK; }
     if (key == 8 && (value == 0 || value == 1)) { g_mg_conv_dot = value; return MG_OK; }
+    if (key == 9 && (value == 3 || value == 4)) { g_mg_conv_halo_ring = value; return MG_OK; }
     return mg_fail(MG_ERR_ARG, "mg_set_option: unknown key/value %d/%d", key, value);
 }

@@ -32,21 +32,31 @@
 #endif
 
 extern int g_mg_conv_halo_big;     // mg_set_option(4, v): 0 = never use the 128 x 16x16 geometry
+extern int g_mg_conv_halo_ring;    // mg_set_option(9, v): weight-slab ring depth of the 128 x 16x16 geometry (3 or 4)
 
 namespace {
 
 constexpr int TW = 16, PW = TW + 2;
 
-template <int WM, int NT> struct HaloGeom {
+// RING = weight slabs in flight + 1.  RING 3: one tap computing, two fetching (the round-1 kernel).  RING 4: three fetching --
+// PMC on the SPADE shape (profiles/r01_pmc_halo_final.txt) put 37 % of the wave cycles in s_waitcnt with the LDS pipe only 22 %
+// busy: the waves wait for the LDS-DMA weight stream, so the prefetch distance grows by one tap.  The fourth 8 KiB slab fits
+// next to two workgroups per CU only if the patch stage stops being rounded up to a multiple of four 1 KiB blocks (21 -> 24
+// at 16x16 pixels): the spare DMA instructions that keep every wave's load count equal now land in one shared 1 KiB dump block.
+template <int WM, int NT, int RING = 3> struct HaloGeom {
     static constexpr int WN = 4 / WM;
     static constexpr int TM = WM * 64;
     static constexpr int TH = WN * NT * 32 / TW;                // 8 or 16
     static constexpr int PROWS = (TH + 2) * PW;
-    static constexpr int PBLK = ((PROWS + 15) / 16 + 3) / 4 * 4;    // whole 16-row blocks, same count per wave
-    static constexpr int PSTAGE = PBLK * 1024;
+    static constexpr int PBLK_REAL = (PROWS + 15) / 16;         // 1 KiB blocks (16 rows of 64 B) the patch really has
+    static constexpr int PBLK = (PBLK_REAL + 3) / 4 * 4;        // DMA instructions issued: the same count by every wave
+    static constexpr bool DUMP = RING > 3 && PBLK != PBLK_REAL; // spare instructions write a shared dump block instead of padding each stage
+    static constexpr int PSTAGE = (DUMP ? PBLK_REAL : PBLK) * 1024;
     static constexpr int ASTAGE = TM * ROWB;
     static constexpr int A_IPS = TM / 64, P_IPS = PBLK / 4;
-    static constexpr int PAR = 3 * ASTAGE + 2 * PSTAGE;          // epilogue channel parameters (2*TM floats)
+    static constexpr int PATCH0 = RING * ASTAGE;                 // byte offset of the first patch stage
+    static constexpr int DUMP_OFF = PATCH0 + 2 * PSTAGE;
+    static constexpr int PAR = DUMP_OFF + (DUMP ? 1024 : 0);     // epilogue channel parameters (2*TM floats)
     static constexpr int LDS = PAR + 2 * TM * 4;
     static constexpr int OCC = NT == 4 ? 2 : 3;                 // waves per SIMD the register budget is set for
 };
@@ -63,10 +73,11 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-template <typename T, int EPI, int WM, int NT>
+template <typename T, int EPI, int WM, int NT, int RING = 3>
 __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(const ConvK d)
 {
-    using G = HaloGeom<WM, NT>;
+    using G = HaloGeom<WM, NT, RING>;
+    constexpr int PF = RING - 1;                               // weight slabs in flight ahead of the tap being computed
     constexpr int MT = 2, WN = G::WN;
     constexpr int TH = G::TH, PROWS = G::PROWS, PSTAGE = G::PSTAGE, ASTAGE = G::ASTAGE, TM_H = G::TM;
     constexpr int A_IPS = G::A_IPS, P_IPS = G::P_IPS;
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
     constexpr int CH  = ROWB / (int)sizeof(T);
     constexpr int KX  = BF ? 32 : 16;                          // byte XOR that selects the lane's second K piece
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring 3 x ASTAGE][patch 2 x PSTAGE]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring RING x ASTAGE][patch 2 x PSTAGE][dump][params]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,10 +134,12 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
     const int nchunk = d.Cin / CH;
 
     auto issue_patch = [&](int buf) {
-        const unsigned base = lds0 + 3 * ASTAGE + buf * PSTAGE;
+        const unsigned base = lds0 + G::PATCH0 + buf * PSTAGE;
 #pragma unroll
         for (int j = 0; j < P_IPS; ++j) {
-            glds16(pp[j], __builtin_amdgcn_readfirstlane(base + (wave + 4 * j) * 1024));
+            const int blk = wave + 4 * j;
+            const unsigned dst = (G::DUMP && blk >= G::PBLK_REAL) ? lds0 + G::DUMP_OFF : base + blk * 1024;   // rows past the patch fetch zeros
+            glds16(pp[j], __builtin_amdgcn_readfirstlane(dst));
             pp[j] += ROWB;
         }
     };
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int brow = ((wn * NT + nt) * 2 + py + 1 + dy) * PW + px + 1 + dx;
-                boff[t][nt] = 3 * ASTAGE + brow * ROWB + ((ksp ^ ((brow >> 2) & 3)) << 4);
+                boff[t][nt] = G::PATCH0 + brow * ROWB + ((ksp ^ ((brow >> 2) & 3)) << 4);
             }
         }
     }
@@ -231,30 +244,58 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
     // epilogue channel parameters (LDS-DMA, the oldest loads of each wave)
     float* const par = reinterpret_cast<float*>(smem + G::PAR);
     conv_stage_params_dma<TM_H, EPI, 4>(d, m0, lds0 + G::PAR, wave, lane);
-    // prologue: patch of chunk 0, weights of taps 0 and 1
+    // prologue: patch of chunk 0, weights of the first PF taps
     issue_patch(0);
-    issue_a(0, false);
-    issue_a(1, false);
-
-    for (int c = 0; c < nchunk; ++c) {
-        const bool next_chunk = (c + 1 < nchunk);
-        const int pdelta = (c & 1) ? -PSTAGE : PSTAGE;          // this tap's patch addresses for the next chunk
-        static_for<0, 9>([&](auto t_) {
-            constexpr int t = decltype(t_)::value;
-            // loads younger than the weights of this tap: next tap's weights (A_IPS per wave) and, right after
-            // a chunk started, the next chunk's patch (P_IPS per wave) -- see the issue order below
-            if constexpr (t == 1 || t == 2) { if (next_chunk) wait_vmcnt<A_IPS + P_IPS>(); else wait_vmcnt<A_IPS>(); }
-            else if constexpr (t == 8)      { if (next_chunk) wait_vmcnt<A_IPS>(); else wait_vmcnt<0>(); }
-            else                            wait_vmcnt<A_IPS>();
-            __builtin_amdgcn_s_barrier();
-            // weights two taps ahead into the ring slot consumed at the previous tap
-            if constexpr (t < 7) issue_a((t + 2) % 3, t == 6);
-            else { if (next_chunk) issue_a((t + 2) % 3, false); }
-            if constexpr (t == 0) { if (next_chunk) issue_patch((c + 1) & 1); }
-            compute(t_, t % 3);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) boff[t][nt] += pdelta;
-        });
+    for (int i = 0; i < PF; ++i) issue_a(i, false);
+
+    if constexpr (RING == 3) {
+        for (int c = 0; c < nchunk; ++c) {
+            const bool next_chunk = (c + 1 < nchunk);
+            const int pdelta = (c & 1) ? -PSTAGE : PSTAGE;          // this tap's patch addresses for the next chunk
+            static_for<0, 9>([&](auto t_) {
+                constexpr int t = decltype(t_)::value;
+                // loads younger than the weights of this tap: next tap's weights (A_IPS per wave) and, right after
+                // a chunk started, the next chunk's patch (P_IPS per wave) -- see the issue order below
+                if constexpr (t == 1 || t == 2) { if (next_chunk) wait_vmcnt<A_IPS + P_IPS>(); else wait_vmcnt<A_IPS>(); }
+                else if constexpr (t == 8)      { if (next_chunk) wait_vmcnt<A_IPS>(); else wait_vmcnt<0>(); }
+                else                            wait_vmcnt<A_IPS>();
+                __builtin_amdgcn_s_barrier();
+                // weights two taps ahead into the ring slot consumed at the previous tap
+                if constexpr (t < 7) issue_a((t + 2) % 3, t == 6);
+                else { if (next_chunk) issue_a((t + 2) % 3, false); }
+                if constexpr (t == 0) { if (next_chunk) issue_patch((c + 1) & 1); }
+                compute(t_, t % 3);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) boff[t][nt] += pdelta;
+            });
+        }
+    } else {
+        // RING 4: tap g = 9 c + t lives in slot g & 3 (9 = 1 mod 4, so the slot of tap t moves by one per chunk: a scalar).
+        // Issue order per wave: ... W(g+1) W(g+2) | tap g: wait W(g), barrier, issue W(g+3) [, patch(c+1) at t = 0], compute.
+        // Loads younger than W(g) when tap g waits: W(g+1), W(g+2) (those that exist) and, at t = 1..3, the next chunk's patch.
+        int s0 = 0;                                               // slot of tap 0 of this chunk
+        for (int c = 0; c < nchunk; ++c) {
+            const bool next_chunk = (c + 1 < nchunk);
+            const int pdelta = (c & 1) ? -PSTAGE : PSTAGE;
+            static_for<0, 9>([&](auto t_) {
+                constexpr int t = decltype(t_)::value;
+                if (next_chunk) {
+                    if constexpr (t >= 1 && t <= 3) wait_vmcnt<2 * A_IPS + P_IPS>(); else wait_vmcnt<2 * A_IPS>();
+                } else {
+                    if constexpr (t <= 6) wait_vmcnt<2 * A_IPS>(); else if constexpr (t == 7) wait_vmcnt<A_IPS>(); else wait_vmcnt<0>();
+                }
+                __builtin_amdgcn_s_barrier();
+                // weights three taps ahead into the slot that was consumed at the previous tap
+                if constexpr (t < 6) issue_a((s0 + t + 3) & 3, t == 5);
+                else { if (next_chunk) issue_a((s0 + t + 3) & 3, false); }
+                if constexpr (t == 0) { if (next_chunk) issue_patch((c + 1) & 1); }
+                compute(t_, (s0 + t) & 3);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) boff[t][nt] += pdelta;
+            });
+            s0 = (s0 + 1) & 3;
+        }
     }
 
     auto pixmap = [&](int p, size_t& opix) -> bool {
@@ -267,16 +308,17 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
     conv_epilogue<T, MT, NT, EPI, TM_H>(d, acc, m0, pixmap, wm, wn, l31, hi, par);
 }
 
-template <typename T, int EPI, int WM, int NT>
+template <typename T, int EPI, int WM, int NT, int RING = 3>
 int launch_halo_g(ConvK& k, hipStream_t st)
 {
-    using G = HaloGeom<WM, NT>;
+    using G = HaloGeom<WM, NT, RING>;
     k.tiles_m = (k.Cout_gemm + G::TM - 1) / G::TM;
     k.tiles_y = (k.Hin + G::TH - 1) / G::TH;
     k.tiles_x = (k.Win + TW - 1) / TW;
     const long nblk = (long)k.N * k.tiles_y * k.tiles_x * k.tiles_m;
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_taps(halo): bad grid %ld", nblk);
-    auto kern = conv3x3_halo_kernel<T, EPI, WM, NT>;
+    static_assert(RING == 3 || 2 * G::LDS <= 160 * 1024, "LDS budget of the deep ring: two workgroups per CU");
+    auto kern = conv3x3_halo_kernel<T, EPI, WM, NT, RING>;
     if constexpr (G::LDS > 65536) {
         static bool attr_done = false;
         if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); attr_done = true; }
@@ -292,7 +334,8 @@ int launch_halo(ConvK& k, hipStream_t st)
     if (k.Cout_gemm <= 64) return launch_halo_g<T, EPI, 1, 2>(k, st);
     // 16x16-pixel tiles once they still give every CU its two workgroups at least twice over
     const long big = (long)k.N * ((k.Hin + 15) / 16) * ((k.Win + 15) / 16) * ((k.Cout_gemm + 127) / 128);
-    if (g_mg_conv_halo_big && k.Hin >= 16 && big >= 1024) return launch_halo_g<T, EPI, 2, 4>(k, st);
+    if (g_mg_conv_halo_big && k.Hin >= 16 && big >= 1024)
+        return g_mg_conv_halo_ring == 4 ? launch_halo_g<T, EPI, 2, 4, 4>(k, st) : launch_halo_g<T, EPI, 2, 4, 3>(k, st);
     return launch_halo_g<T, EPI, 2, 2>(k, st);
 }
 
