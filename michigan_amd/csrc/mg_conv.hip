@@ -16,7 +16,7 @@
 // (exact fp32 fma chain) -- same tiling, same LDS image (64 B of K per row).
 
 int g_mg_conv_splitk = 1;        // deterministic split-K for low-resolution long-K layers (mg_set_option(5, v))
-int g_mg_conv_halo_ring = 4;     // weight-slab ring of the big halo tile: 3 = two taps in flight, 4 = three (mg_set_option(9, v))
+int g_mg_conv_halo_ring = 3;     // weight-slab ring of the big halo tile: 3 = two taps in flight, 4 = three (mg_set_option(9, v)); measured equal (profiles/r02_halo_ring_ab.txt)
 int g_mg_conv_halo_big = 1;      // 128 channels x 16x16 pixel halo tiles where the launch is big enough (mg_set_option(4, v))
 int g_mg_conv_halo = 1;          // 3x3 stride-1 convs on the LDS halo-tile kernel (mg_set_option(2, v))
 int g_mg_conv_bigtiles = 1;      // allow the 128x256 / 256x256 tiles (mg_set_option(1, v))

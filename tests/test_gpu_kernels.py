@@ -787,6 +787,7 @@ def test_batched_spectral_norm_and_pack_match_contract(dt):
     (hip, _), (ref, _) = _both(fn, (x, seg, gy))
     for i in range(4):
         _close(f"batched weights {dt}: output of pass {i}", hip[i], ref[i], 5e-4 if dt == "f32" else 2.0 ** -5)
-    _close(f"batched weights {dt}: u", hip[4], ref[4], 1e-4)
-    _close(f"batched weights {dt}: v", hip[5], ref[5], 1e-4)
+    # u, v after three optimiser steps: the weights they were iterated on already differ by a few sign-like Adam updates in bf16
+    _close(f"batched weights {dt}: u", hip[4], ref[4], 1e-4 if dt == "f32" else 5e-3)
+    _close(f"batched weights {dt}: v", hip[5], ref[5], 1e-4 if dt == "f32" else 5e-3)
     assert ((hip[6].cpu() - ref[6]).abs() > 2.5e-3).float().mean() < 0.01       # Adam (lr 1e-3): sign-like updates, see trainer_parity.compare
