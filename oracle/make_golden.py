@@ -123,8 +123,69 @@ def make_trainer(tags=("A", "B")):
         json.dump(TP.CFGS, fh)
 
 
+C0_CFG = dict(sample="67172", crop=512, add_th=64, seed_g=51, seed_ig=53, seed_noise=57, gain=1.0, window=192)
+
+
+def config0_inputs(fx):
+    """The loader dict of BASELINE configs[0] rebuilt from the compact fixture (u8 planes) with the loader's own arithmetic
+    (ToTensor = u8 / 255, Normalize = (t - 0.5) / 0.5, label * 255): bit-identical to what the reference's loader produced."""
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float()
+    img = (f(fx["image_u8"]).div(255) - 0.5) / 0.5
+    noise = torch.rand(1, 3, C0_CFG["crop"], C0_CFG["crop"], generator=torch.Generator().manual_seed(C0_CFG["seed_noise"]))
+    return {"label_ref": f(fx["label_u8"])[None], "label_tag": f(fx["label_u8"])[None], "instance": torch.tensor(0),
+            "image_ref": img[None], "image_tag": img[None].clone(), "path": "67172.jpg", "orient": f(fx["orient_u8"])[None],
+            "hole": f(fx["hole_u8"])[None], "orient_rgb": f(fx["orient_rgb_u8"]).div(255)[None] * f(fx["label_u8"])[None], "noise": noise}
+
+
+def make_config0():
+    """BASELINE.json configs[0] as written: the README inference command (README.md:51) on the bundled sample 67172 --
+    the reference's own option parser, loader (`single_inference_dataLoad`, data/base_dataset.py:49-160), Pix2PixModel in
+    eval mode with --use_ig (frozen in-painting net) and --add_feat_zeros (576 x 576 canvas), random-init weights from seeds
+    (the trained checkpoints are downloads).  The loader's multi-octave noise field (cv2.resize, absent here) is replaced by a
+    seeded uniform field of the same range so that it need not be stored; everything else is the loader's output."""
+    import tempfile
+    R.setup()
+    from data.base_dataset import single_inference_dataLoad
+    from models.pix2pix_model import Pix2PixModel
+    with tempfile.TemporaryDirectory() as ck:
+        opt = R.reference_options(R.README_INFERENCE_FLAGS + ["--data_dir", os.path.join(R.REFERENCE_ROOT, "datasets", "FFHQ_single"),
+                                                              "--checkpoints_dir", ck], train=False)
+        random.seed(0)
+        np.random.seed(0)
+        d = single_inference_dataLoad(opt)
+        u8 = lambda t: np.round(t.numpy()).astype(np.uint8)
+        lab = d["label_tag"][0]
+        fx = {"label_u8": u8(lab), "orient_u8": u8(d["orient"][0]), "hole_u8": u8(d["hole"][0]),
+              "image_u8": u8((d["image_tag"][0] * 0.5 + 0.5) * 255)}
+        with np.errstate(invalid="ignore"):
+            fx["orient_rgb_u8"] = u8(torch.where(lab > 0, d["orient_rgb"][0] / lab.clamp_min(1e-9), torch.zeros(())) * 255)
+        data = config0_inputs(fx)
+        for k in ("label_tag", "label_ref", "orient", "hole", "image_tag", "image_ref", "orient_rgb"):      # the compact form is lossless
+            assert torch.equal(data[k], d[k].float()), k
+        R.write_inpaint_checkpoint(opt, seed=C0_CFG["seed_ig"], gain=C0_CFG["gain"])
+        torch.manual_seed(0)
+        model = Pix2PixModel(opt)
+        model.netG.load_state_dict(synth_state_dict(model.netG.state_dict(), seed=C0_CFG["seed_g"], gain=C0_CFG["gain"]))
+        model.eval()
+        with torch.no_grad():
+            out = model({k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()}, mode="inference")
+    o, w = C0_CFG["add_th"] // 2, C0_CFG["window"]
+    c = o + (C0_CFG["crop"] - w) // 2
+    fx.update({"out_window": out[0, :, c:c + w, c:c + w].numpy().astype(np.float32),
+               "out_rowsum": out[0].double().sum(2).numpy(), "out_colsum": out[0].double().sum(1).numpy(),
+               "out_shape": np.array(out.shape)})
+    np.savez_compressed(os.path.join(OUT, "config0_67172.npz"), **fx)
+    with open(os.path.join(OUT, "config0_config.json"), "w") as fh:
+        json.dump(C0_CFG, fh)
+    print("config0 golden: out", tuple(out.shape), "mean %.4f std %.4f" % (out.mean().item(), out.std().item()),
+          "fixture %.2f MB" % (os.path.getsize(os.path.join(OUT, "config0_67172.npz")) / 1e6))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--config0" in sys.argv:
+        make_config0()
+        return
     if "--trainer" in sys.argv:            # only these fixtures
         make_trainer()
         return

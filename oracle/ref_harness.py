@@ -42,18 +42,81 @@ def _vgg19_stub(pretrained=False, **_):
     return m
 
 
+class _Compose:
+    def __init__(self, ts):
+        self.ts = list(ts)
+
+    def __call__(self, x):
+        for t in self.ts:
+            x = t(x)
+        return x
+
+
+class _Lambda:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, x):
+        return self.fn(x)
+
+
+class _Resize:
+    def __init__(self, size, interpolation=None):
+        self.size, self.interpolation = size, interpolation
+
+    def __call__(self, img):
+        h, w = self.size if isinstance(self.size, (list, tuple)) else (self.size, self.size)
+        return img.resize((w, h), self.interpolation)
+
+
+class _ToTensor:
+    """torchvision.transforms.ToTensor: PIL image / HWC uint8 array -> CHW float in [0, 1] (uint8 inputs are divided by 255)."""
+
+    def __call__(self, pic):
+        import numpy as np
+        a = np.asarray(pic)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        t = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
+        return t.float().div(255) if t.dtype == torch.uint8 else t.float()
+
+
+class _Normalize:
+    def __init__(self, mean, std):
+        self.mean, self.std = torch.tensor(mean).view(-1, 1, 1), torch.tensor(std).view(-1, 1, 1)
+
+    def __call__(self, t):
+        return (t - self.mean) / self.std
+
+
+class _Identity:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, x):
+        return x
+
+
 def _install_stubs():
+    """Functional stand-ins for the third-party modules the reference imports and this container lacks (torchvision, cv2,
+    dominate): enough of their published behaviour for the reference's loader / model code paths the fixtures exercise."""
     if "torchvision" not in sys.modules:
         tv = types.ModuleType("torchvision")
         tvm = types.ModuleType("torchvision.models")
         tvm.vgg19 = _vgg19_stub
         tvt = types.ModuleType("torchvision.transforms")
-        for name in ("Compose", "Lambda", "Resize", "ToTensor", "Normalize", "ColorJitter"):
-            setattr(tvt, name, type(name, (), {"__init__": lambda self, *a, **k: None}))
+        tvt.Compose, tvt.Lambda, tvt.Resize, tvt.ToTensor, tvt.Normalize, tvt.ColorJitter = _Compose, _Lambda, _Resize, _ToTensor, _Normalize, _Identity
         tv.models, tv.transforms = tvm, tvt
         sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.transforms": tvt})
     if "cv2" not in sys.modules:
-        sys.modules["cv2"] = types.ModuleType("cv2")
+        cv2 = types.ModuleType("cv2")
+        cv2.INTER_LINEAR = 1
+
+        def resize(src, dsize, interpolation=1, **_):
+            from oracle.inputs_oracle import cv2_resize_linear           # restated from OpenCV's published algorithm (parity-unpinned)
+            return cv2_resize_linear(src, dsize)
+        cv2.resize = resize
+        sys.modules["cv2"] = cv2
     if "dominate" not in sys.modules:
         dm = types.ModuleType("dominate")
         dmt = types.ModuleType("dominate.tags")
@@ -80,6 +143,9 @@ def setup():
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     _adam_float_betas()
+    import numpy as np
+    if not hasattr(np, "float"):
+        np.float = float                      # data/base_dataset.py:358 (removed from numpy 1.24; SURVEY.md section 8c shim 4)
     _ready = True
 
 
@@ -188,3 +254,9 @@ def write_inpaint_checkpoint(opt, seed: int = 7, gain: float = 1.0):
     os.makedirs(d, exist_ok=True)
     torch.save({"generator": sd}, os.path.join(d, opt.ig_model_name))
     return sd
+
+
+# README "Inference" command (README.md:51) on the bundled sample 67172 = BASELINE.json configs[0]
+README_INFERENCE_FLAGS = ("--name MichiGAN --gpu_ids -1 --inference_ref_name 67172 --inference_tag_name 67172 --inference_orient_name 67172 "
+                          "--netG spadeb --which_epoch 50 --use_encoder --noise_background --expand_mask_be --expand_th 5 --use_ig "
+                          "--load_size 512 --crop_size 512 --add_feat_zeros").split()

@@ -171,3 +171,41 @@ def run_inference_config0(device, dtype=torch.float32):
     out = model(data, mode="inference")
     o, cs = cfg["add_th"] // 2, cfg["crop_size"]
     return {"out_padded": out.float().cpu().numpy(), "out": out[:, :, o:o + cs, o:o + cs].float().cpu().numpy()}   # inference.py:44-48
+
+
+def config0_fixture():
+    """(loader dict, fixture, config) of BASELINE configs[0] on the bundled sample 67172 (oracle/make_golden.py --config0)."""
+    from oracle.make_golden import C0_CFG, config0_inputs
+    fx = golden("config0_67172.npz")
+    return config0_inputs(fx), fx, C0_CFG
+
+
+def compare_config0(out, fx, cfg, *, atol, rtol_sum):
+    """`out` [1,3,576,576] against the reference's image: the central window element-wise (L_inf), the whole canvas through
+    its row / column sums."""
+    assert tuple(out.shape) == tuple(fx["out_shape"])
+    out = out.detach().float().cpu()
+    o, w = cfg["add_th"] // 2, cfg["window"]
+    c = o + (cfg["crop"] - w) // 2
+    err = np.abs(out[0, :, c:c + w, c:c + w].numpy() - fx["out_window"]).max()
+    rs = np.abs(out[0].double().sum(2).numpy() - fx["out_rowsum"]).max() / np.abs(fx["out_rowsum"]).max()
+    cs = np.abs(out[0].double().sum(1).numpy() - fx["out_colsum"]).max() / np.abs(fx["out_colsum"]).max()
+    print("configs[0] sample 67172: window L_inf %.3e, row-sum rel %.3e, col-sum rel %.3e" % (err, rs, cs))
+    assert err < atol and rs < rtol_sum and cs < rtol_sum, (err, rs, cs)
+
+
+def run_config0_repo_model(device, dtype="fp32"):
+    """michigan_amd.model.Pix2PixModel(mode='inference') under the README inference flags (README.md:51)."""
+    from michigan_amd.model import Pix2PixModel, default_options
+    from michigan_amd.synth import synth_state_dict
+    data, fx, cfg = config0_fixture()
+    opt = default_options(crop_size=cfg["crop"], add_feat_zeros=True, add_th=cfg["add_th"], isTrain=False, use_ig=True,
+                          inpaint_orient=True, expand_mask_be=True, expand_th=5, random_expand_mask=False,
+                          gpu_ids=[0] if device != "cpu" else [], compute_dtype=dtype)
+    torch.manual_seed(0)
+    model = Pix2PixModel(opt)
+    model.netG.load_state_dict(synth_state_dict(model.netG.state_dict(), seed=cfg["seed_g"], gain=cfg["gain"]))
+    model.netIG.load_state_dict(synth_state_dict(model.netIG.state_dict(), seed=cfg["seed_ig"], gain=cfg["gain"]))
+    model.to(device).eval()
+    out = model({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in data.items()}, mode="inference")
+    return out, fx, cfg

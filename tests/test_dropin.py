@@ -163,3 +163,25 @@ def test_batched_weight_paths_equal_per_layer_paths(emulator_backend):
             assert np.abs(a - b).max() < 1e-4 * np.abs(b).max(), k
         elif k.startswith(("G.", "D.")):
             assert (np.abs(a - b) > 2 * 4e-4 * 2 + 1e-5).mean() < 0.005, k
+
+
+@needs_reference
+def test_config0_reference_inference_over_hip_classes(dropin_installed):
+    """BASELINE configs[0] through the reference's OWN inference path (option parser, single_inference_dataLoad's dict,
+    Pix2PixModel(mode='inference'), util.load_inpainting_network) with the HIP classes patched in; vs the unmodified run."""
+    import parity_utils as PU
+    from models.pix2pix_model import Pix2PixModel
+    from michigan_amd import networks as hip
+    from michigan_amd.synth import synth_state_dict
+    data, fx, cfg = PU.config0_fixture()
+    with tempfile.TemporaryDirectory() as ck:
+        opt = R.reference_options(R.README_INFERENCE_FLAGS + ["--data_dir", "unused", "--checkpoints_dir", ck], train=False)
+        R.write_inpaint_checkpoint(opt, seed=cfg["seed_ig"], gain=cfg["gain"])
+        torch.manual_seed(0)
+        model = Pix2PixModel(opt)
+    assert isinstance(model.netG, hip.SPADEBGenerator) and isinstance(model.netIG, hip.InpaintGenerator)
+    model.netG.load_state_dict(synth_state_dict(model.netG.state_dict(), seed=cfg["seed_g"], gain=cfg["gain"]))
+    model.eval()
+    with torch.no_grad():
+        out = model(data, mode="inference")
+    PU.compare_config0(out, fx, cfg, atol=2e-4, rtol_sum=1e-5)
