@@ -65,7 +65,15 @@ class ConvMeter:
             orig(inp, wt, out, bias, taps, **kw)
             e.record()
             flops = 2.0 * inp.shape[0] * kw["Hj"] * kw["Wj"] * kw["cout_gemm"] * kw.get("algo_cin", inp.shape[3]) * len(taps)
-            recs.append((s, e, flops, inp.dtype))
+            n, h, w = inp.shape[0], inp.shape[1], inp.shape[2]
+            # the launches mg_conv_taps routes to conv3x3_halo_kernel<bf16, SPADE, 2, 4> (mg_conv_halo.hip launch_halo): fused
+            # gamma|beta conv + modulation, more than 64 GEMM rows, 16x16-pixel tiles filling the chip
+            dominant = (kw.get("spade_x") is not None and len(taps) == 9 and kw["cout_gemm"] > 64 and h >= 16 and inp.shape[3] % 32 == 0
+                        and n * ((h + 15) // 16) * ((w + 15) // 16) * ((kw["cout_gemm"] + 127) // 128) >= 1024)
+            # conv-granular algorithmic bytes of a SPADE launch: activation map in, x in, h (+ 1+gamma when training) out, weights
+            g1 = kw.get("gamma_out")
+            abytes = (inp.numel() + 2 * out.numel() + (out.numel() if g1 is not None else 0) + wt.numel()) * inp.element_size() if dominant else 0
+            recs.append((s, e, flops, inp.dtype, dominant, abytes))
         self.ops._launch_conv = timed
         return self
 
@@ -74,9 +82,10 @@ class ConvMeter:
 
     def summary(self):
         torch.cuda.synchronize()
-        ms = sum(s.elapsed_time(e) for s, e, _, _ in self.records)
-        fl = sum(f for _, _, f, _ in self.records)
-        return len(self.records), ms, fl
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        fl = sum(r[2] for r in self.records)
+        dom = [r for r in self.records if r[4]]
+        return len(self.records), ms, fl, (len(dom), sum(r[0].elapsed_time(r[1]) for r in dom), sum(r[2] for r in dom), sum(r[5] for r in dom))
 
 
 def self_spawn(a) -> int:
@@ -172,20 +181,35 @@ def main():
         _par.reset_collective_counts()
         with ConvMeter() as m:
             step()
-        n, ms, fl = m.summary()
+        n, ms, fl, (dn, dms, dfl, dbytes) = m.summary()
         collectives = dict(_par.COLLECTIVES)
         if rank == 0:
             peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
             ach = fl / (ms * 1e-3) / 1e12
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")     # tools/pmc_step.sh (rocprofv3 --pmc passes)
+            all_conv = {"kernels": "every mg_conv_taps launch of one step (forward + data gradients)", "launches": n,
+                        "achieved": round(ach, 1), "frac": round(ach / peak, 4), "kernel_ms_per_step": round(ms, 3),
+                        "algorithmic_gflop_per_step": round(fl / 1e9, 1)}
+            if dn:
+                # dominant kernel (most time per step in the rocprofv3 kernel stats): the fused SPADE gamma|beta conv + modulation
+                dach = dfl / (dms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "kernel": "conv3x3_halo_kernel<bf16, SPADE, 2, 4>", "achieved": round(dach, 1), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(dach / peak, 4), "launches_per_step": dn,
+                        "avg_launch_us": round(dms / dn * 1e3, 1), "algorithmic_gflop_per_launch": round(dfl / dn / 1e9, 1),
+                        "algorithmic_gb_per_launch": round(dbytes / dn / 1e9, 3),
+                        "traffic": None, "all_conv_launches": all_conv}
+            else:
+                roof = {"bound": "mfma", "kernel": "all mg_conv_taps launches", "achieved": all_conv["achieved"], "peak": peak,
+                        "unit": "TFLOP/s", "frac": all_conv["frac"], "traffic": None, "all_conv_launches": all_conv}
+            tfile = os.path.join(ROOT, "profiles", "r02_conv_traffic.json")     # tools/pmc_step.sh (rocprofv3 --pmc passes, separate runs)
             if a.mode == "train" and a.dtype == "bf16" and a.batch_per_gpu == 8 and a.size == 512 and os.path.exists(tfile):
                 with open(tfile) as fh:
-                    traffic = round(json.load(fh)["conv"]["hbm_bytes_per_step"] / 1e9, 2)
-            roof = {"bound": "mfma", "kernel": "conv3x3_halo_kernel + conv_taps_glds_kernel (all fwd + dgrad conv launches of one step)",
-                    "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "traffic": traffic, "traffic_unit": "GB of HBM per step for the same launches (2*FETCH_SIZE + WRITE_SIZE)",
-                    "launches": n, "kernel_ms_per_step": round(ms, 3), "algorithmic_gflop_per_step": round(fl / 1e9, 1)}
+                    tj = json.load(fh)
+                dk = tj.get("dominant")
+                if dk and dn:
+                    roof["traffic"] = round(dk["hbm_bytes_per_launch"] / 1e9, 3)
+                    roof["traffic_unit"] = "GB of HBM per launch of the same kernel (2*FETCH_SIZE + WRITE_SIZE)"
+                all_conv["traffic_gb_per_step"] = round(tj["conv"]["hbm_bytes_per_step"] / 1e9, 2)
+                roof["traffic_source"] = "profiles/r02_conv_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit " + str(tj.get("commit"))
     if world > 1:
         dist.barrier()
 
