@@ -145,7 +145,7 @@ class HipBackend:
             import sys
             print("[michigan_amd] libmichigan_hip.so missing: building it with hipcc (gfx950), ~2 min", file=sys.stderr, flush=True)
             from . import build as _build
-            _build.build(verbose=False)
+            _build.build_locked(verbose=False)          # one process builds, the other ranks of a one-process-per-GPU launch wait
         if not os.path.exists(path):
             raise RuntimeError(
                 f"libmichigan_hip.so not found at {path}: build it with "

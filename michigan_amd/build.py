@@ -79,15 +79,30 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH, *objs]
+    tmp_lib = LIB_PATH + ".tmp.%d" % os.getpid()             # link aside and rename: a concurrent dlopen never sees a partial file
+    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp_lib, *objs]
     if verbose:
         print("[michigan_amd.build]", " ".join(link), flush=True)
     res = subprocess.run(link, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"link failed:\n{res.stdout}\n{res.stderr}")
+    os.replace(tmp_lib, LIB_PATH)
     with open(stamp, "w") as fh:
         fh.write(fp)
     return LIB_PATH
+
+
+def build_locked(force: bool = False, verbose: bool = True) -> str:
+    """build() under an exclusive file lock on lib/: when every rank of a multi-process launch finds the library missing,
+    one compiles and the others block here and then find the stamp up to date."""
+    import fcntl
+    os.makedirs(LIB_DIR, exist_ok=True)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return build(force=force, verbose=verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 if __name__ == "__main__":

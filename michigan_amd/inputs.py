@@ -94,17 +94,17 @@ def crop_u8(src: torch.Tensor, crop: torch.Tensor, size, *, mode: int, unknown_l
         src = src.unsqueeze(-1)
     n, hs, ws, c = src.shape
     h, w = (size, size) if isinstance(size, int) else size
-    crop = crop.to(device=src.device, dtype=torch.int32).contiguous()
-    if crop.shape != (n, 3):
+    if tuple(crop.shape) != (n, 3):
         raise ValueError("crop must be [N, 3] = (x0, y0, flip)")
+    crop_host = crop if not crop.is_cuda else None      # the window is validated on the host BEFORE it is uploaded (the draws are made there)
+    crop = crop.to(device=src.device, dtype=torch.int32).contiguous()
     if mul is not None:
         mul = mul.to(torch.float32).contiguous()
         if mul.numel() != n * h * w:
             raise ValueError("mul must be [N, 1, H, W]")
     lim_h = hs if ytab is None else ytab.numel()
     lim_w = ws if xtab is None else xtab.numel()
-    cr = crop.cpu() if not crop.is_cuda else None
-    if cr is not None and (int(cr[:, 1].max()) + h > lim_h or int(cr[:, 0].max()) + w > lim_w or int(cr.min()) < 0):
+    if crop_host is not None and (int(crop_host[:, 1].max()) + h > lim_h or int(crop_host[:, 0].max()) + w > lim_w or int(crop_host.min()) < 0):
         raise ValueError("crop window outside the (resized) source")
     out = torch.empty((n, c, h, w), dtype=torch.float32, device=src.device)
     C.backend().mg_input_crop_u8(_p(src), _p(out), _p(crop), _p(ytab), _p(xtab), _p(mul), n, hs, ws, c, h, w,
@@ -208,7 +208,10 @@ class DeviceInputPipeline:
             if key not in self._btabs:
                 self._btabs[key] = (bicubic_table(key[1], self.load_size, dev), bicubic_table(key[0], self.load_size, dev))
             image = resize_bicubic_u8(image, self.load_size, self._btabs[key])
-        crop = self.draw_params(n).to(dev)
+        crop_h = self.draw_params(n)
+        if int(crop_h[:, :2].min()) < 0 or int(crop_h[:, :2].max()) + cs > self.load_size:      # checked on the host, before the upload
+            raise ValueError("crop window outside the load_size x load_size source")
+        crop = crop_h.to(dev)
         yt, xt = self._tab(label.shape[1]), self._tab(label.shape[2])
         unknown = int(opt.label_nc)
         label_t = crop_u8(label, crop, cs, mode=1, unknown_label=unknown, ytab=yt, xtab=xt)

@@ -38,7 +38,7 @@ def default_options(**over) -> argparse.Namespace:
         n_layers_D=4, contain_dontcare_label=False, no_instance=True, no_ganFeat_loss=False, no_vgg_loss=False,
         no_gan_loss=False, init_type="xavier", init_variance=0.02, remove_background=False, wide_edge=2.0,
         gan_mode="hinge", lambda_feat=1.0, lambda_vgg=1.0, lr=0.0002, beta1=0.5, beta2=0.999, no_TTUR=False,
-        compute_dtype="bf16", curr_step=1, niter=50, niter_decay=0,
+        compute_dtype="bf16", curr_step=1, niter=50, niter_decay=0, checkpoints_dir="./checkpoints", name="MichiGAN",
         no_orient_loss=False, no_confidence_loss=True, lambda_orient=10.0, lambda_confidence=100.0, orient_filter="gabor",
         # run the frozen in-painting net on (hole, orient_rgb, noise) like the reference does under --use_ig
         # (pix2pix_model.py:260-263); off by default: BASELINE configs[1-3] feed the orientation map directly
@@ -231,6 +231,33 @@ class Pix2PixModel(nn.Module):
                 return self.generate_fake(self._maybe_inpaint(d))
         raise ValueError("|mode| is invalid")
 
+    # -- checkpoints (the reference's files: util/util.py:195-218, models/pix2pix_model.py:147-156,176-190) ----------------
+    def _ckpt_path(self, label, epoch):
+        import os
+        return os.path.join(self.opt.checkpoints_dir, self.opt.name, "%s_net_%s.pth" % (epoch, label))
+
+    def save(self, epoch):
+        """`<epoch>_net_G.pth` / `<epoch>_net_D.pth`: plain state_dicts with the reference's keys, loadable by the reference."""
+        import os
+        os.makedirs(os.path.join(self.opt.checkpoints_dir, self.opt.name), exist_ok=True)
+        for label, net in (("G", self.netG), ("D", self.netD)):
+            if net is not None:
+                torch.save({k: v.detach().cpu() for k, v in net.state_dict().items()}, self._ckpt_path(label, epoch))
+
+    def load(self, epoch):
+        """util.load_network semantics: copy by key, skip unknown keys, strip a leading 'module.' (multi-GPU files).  The
+        parameters are updated in place, so flat optimiser arenas stay attached."""
+        import os
+        for label, net in (("G", self.netG), ("D", self.netD)):
+            path = self._ckpt_path(label, epoch)
+            if net is None or not os.path.exists(path):
+                continue
+            own = net.state_dict()
+            for key, val in torch.load(path, map_location="cpu").items():
+                key = key[7:] if key.startswith("module.") else key
+                if key in own:
+                    own[key].copy_(val)
+
     def create_optimizers(self, opt, group=None):
         if opt.no_TTUR:
             betas, g_lr, d_lr = (opt.beta1, opt.beta2), opt.lr, opt.lr
@@ -285,6 +312,27 @@ class Pix2PixTrainer:
 
     def get_latest_losses(self):
         return {**self.g_losses, **self.d_losses}
+
+    def save(self, epoch):
+        """trainers/pix2pix_trainer.py:93-94 + the optimiser state the reference does not keep (exp_avg / exp_avg_sq / step in
+        torch.optim.Adam's state_dict layout, `<epoch>_optim.pth`), so that training resumes exactly."""
+        import os
+        self.pix2pix_model_on_one_gpu.save(epoch)
+        if parallel.rank() == 0:
+            torch.save({"G": self.optimizer_G.state_dict(), "D": self.optimizer_D.state_dict(), "old_lr": self.old_lr},
+                       os.path.join(self.opt.checkpoints_dir, self.opt.name, "%s_optim.pth" % epoch))
+
+    def load(self, epoch):
+        import os
+        self.pix2pix_model_on_one_gpu.load(epoch)
+        for o in (self.optimizer_G, self.optimizer_D):
+            o.weight_epoch += 1                      # parameters were rewritten in place: packed weight images are stale
+        path = os.path.join(self.opt.checkpoints_dir, self.opt.name, "%s_optim.pth" % epoch)
+        if os.path.exists(path):
+            sd = torch.load(path, map_location="cpu")
+            self.optimizer_G.load_state_dict(sd["G"])
+            self.optimizer_D.load_state_dict(sd["D"])
+            self.old_lr = sd.get("old_lr", self.old_lr)
 
     def get_latest_generated(self):
         return self.generated

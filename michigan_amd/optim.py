@@ -326,6 +326,36 @@ class FlatAdam:
                 torch.cuda.current_stream().wait_stream(self._stream)
         self.drain_grads()
 
+    # ---- checkpointing ----------------------------------------------------------------------
+    def state_dict(self):
+        """torch.optim.Adam's layout (state per parameter index in registration order: step / exp_avg / exp_avg_sq), so the
+        file interchanges with a torch.optim.Adam over the same parameter list."""
+        state = {}
+        for i, p in enumerate(self.params):
+            a, b = self._span_of[id(p)]
+            state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[a:b].view(p.shape).detach().cpu().clone(),
+                        "exp_avg_sq": self.exp_avg_sq[a:b].view(p.shape).detach().cpu().clone()}
+        group = {"lr": self.param_groups[0]["lr"], "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        group = sd["param_groups"][0]
+        self.param_groups[0]["lr"] = group["lr"]
+        self.betas, self.eps = (float(group["betas"][0]), float(group["betas"][1])), group["eps"]
+        steps = set()
+        for i, p in enumerate(self.params):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            a, b = self._span_of[id(p)]
+            self.exp_avg[a:b].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[a:b].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError("FlatAdam.load_state_dict: parameters with different step counts")
+        self.step_count = steps.pop() if steps else 0
+
     # ---- update -------------------------------------------------------------------------
     def step(self):
         self.sync_grads()

@@ -38,6 +38,10 @@ def init(group=None):
     return _GROUP
 
 
+def rank() -> int:
+    return dist.get_rank(_GROUP) if _GROUP is not None else 0
+
+
 def world_size() -> int:
     return dist.get_world_size(_GROUP) if _GROUP is not None else 1
 

@@ -185,3 +185,34 @@ def test_config0_reference_inference_over_hip_classes(dropin_installed):
     with torch.no_grad():
         out = model(data, mode="inference")
     PU.compare_config0(out, fx, cfg, atol=2e-4, rtol_sum=1e-5)
+
+
+def test_checkpoint_round_trip_resumes_exactly(emulator_backend, tmp_path):
+    """save(epoch) / load(epoch) in the reference's checkpoint format (`<epoch>_net_{G,D}.pth` state_dicts,
+    util/util.py:195-218) + the flat optimiser's Adam state: a trainer restored from the files takes the same next step."""
+    from michigan_amd.model import Pix2PixTrainer
+    from michigan_amd.synth import synth_loader_batch
+    cfg = dict(TP.CFGS["A"], crop=64)
+    opts = lambda: TP.repo_options(cfg, ngf=8, ndf=8, checkpoints_dir=str(tmp_path), name="rt")
+    data = synth_loader_batch(1, 64, seed=9)
+    import random
+    torch.manual_seed(0)
+    a = Pix2PixTrainer(opts())
+    random.seed(1); a.run_generator_one_step(dict(data)); a.run_discriminator_one_step(dict(data))
+    a.save("latest")
+    sd = torch.load(os.path.join(str(tmp_path), "rt", "latest_net_G.pth"))
+    assert list(sd.keys()) == list(a.pix2pix_model.netG.state_dict().keys())
+    torch.manual_seed(123)
+    b = Pix2PixTrainer(opts())                                  # different init
+    b.load("latest")
+    b.pix2pix_model.criterionVGG.vgg.load_state_dict(a.pix2pix_model.criterionVGG.vgg.state_dict())   # the (frozen) loss network is not part of a checkpoint
+    assert b.optimizer_G.step_count == 1 and torch.equal(b.optimizer_G.exp_avg_sq, a.optimizer_G.exp_avg_sq)
+    for t in (a, b):
+        random.seed(2); t.run_generator_one_step(dict(data)); t.run_discriminator_one_step(dict(data))
+    # `a` runs its second iteration on the batched weight paths, the restored `b` its first on the per-layer ones (they differ in
+    # the last bits): the same step up to rounding -- losses to 1e-6, weights within one sign-like Adam update on < 1 % of elements
+    for k in a.get_latest_losses():
+        x, y = float(a.get_latest_losses()[k]), float(b.get_latest_losses()[k])
+        assert abs(x - y) <= 1e-5 * max(abs(x), 0.1), k
+    for oa, ob in ((a.optimizer_G, b.optimizer_G), (a.optimizer_D, b.optimizer_D)):
+        assert ((oa.flat - ob.flat).abs() > 1e-6).float().mean() < 0.01
