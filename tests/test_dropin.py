@@ -215,4 +215,4 @@ def test_checkpoint_round_trip_resumes_exactly(emulator_backend, tmp_path):
         x, y = float(a.get_latest_losses()[k]), float(b.get_latest_losses()[k])
         assert abs(x - y) <= 1e-5 * max(abs(x), 0.1), k
     for oa, ob in ((a.optimizer_G, b.optimizer_G), (a.optimizer_D, b.optimizer_D)):
-        assert ((oa.flat - ob.flat).abs() > 1e-6).float().mean() < 0.01
+        assert ((oa.flat - ob.flat).abs() > 2e-5).float().mean() < 0.01           # 2e-5 = a fifth of one update (lr 1e-4)
