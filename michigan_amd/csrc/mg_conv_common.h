@@ -199,7 +199,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
                     }
                 }
                 bool wide = false;
-                if constexpr (sizeof(T) == 2) wide = d.wide != 0;
+                if constexpr (sizeof(T) == 2) wide = (d.wide & 1) != 0;
                 if (wide) {
                     if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -234,7 +234,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
 #pragma unroll
                 for (int q = 0; q < 2; ++q) xv[nt][q] = ET<T>::load4(X + opix[nt] + (oc[q] < d.Cout ? oc[q] : 0));
             bool wide = false;
-            if constexpr (sizeof(T) == 2) wide = d.wide != 0;
+            if constexpr (sizeof(T) == 2) wide = (d.wide & 1) != 0;
             if (wide) {
                 if constexpr (sizeof(T) == 2) {
                     f32x4_t bg[2], bb[2], mean4[2], rstd4[2];

@@ -305,6 +305,10 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
         opix = (size_t)((img * d.Hout + y) * d.Wout + x);
         return true;
     };
+    if (d.wide & 2) {                            // measurement aid (mg_set_option(10, 1)): main loop only; one store keeps the MFMAs alive
+        if (acc[0][0][0] == 12345.678f) reinterpret_cast<T*>(d.out)[0] = (T)1;
+        return;
+    }
     conv_epilogue<T, MT, NT, EPI, TM_H>(d, acc, m0, pixmap, wm, wn, l31, hi, par);
 }
 

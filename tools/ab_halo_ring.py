@@ -31,8 +31,9 @@ for name, cin, cout, hw, spade in SHAPES:
     res = {}
     with torch.no_grad():
         for rep in range(2):
-            for ring in (3, 4):
-                be.mg_set_option(9, ring)
+            for ring in (3, 4, 13):               # 13 = ring 3 without the epilogue (mg_set_option(10, 1)): main-loop time alone
+                be.mg_set_option(9, 3 if ring == 13 else ring)
+                be.mg_set_option(10, 1 if ring == 13 else 0)
                 for _ in range(3): fn()
                 torch.cuda.synchronize()
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -40,7 +41,9 @@ for name, cin, cout, hw, spade in SHAPES:
                 for _ in range(10): fn()
                 e.record(); torch.cuda.synchronize()
                 res.setdefault(ring, []).append(s.elapsed_time(e) / 10)
-    print(f"{name:36s} ring3 {min(res[3])*1e3:7.1f} us {flops/min(res[3])/1e9:7.1f} TF/s | ring4 {min(res[4])*1e3:7.1f} us {flops/min(res[4])/1e9:7.1f} TF/s", flush=True)
+    be.mg_set_option(10, 0)
+    print(f"{name:36s} ring3 {min(res[3])*1e3:7.1f} us {flops/min(res[3])/1e9:7.1f} TF/s | ring4 {min(res[4])*1e3:7.1f} us {flops/min(res[4])/1e9:7.1f} TF/s"
+          f" | no epilogue {min(res[13])*1e3:7.1f} us {flops/min(res[13])/1e9:7.1f} TF/s", flush=True)
 
 opt = default_options(crop_size=512, gpu_ids=[0], compute_dtype="bf16")
 tr = Pix2PixTrainer(opt)
@@ -48,7 +51,8 @@ data = {k: v.cuda() for k, v in synth_batch(8, 512, seed=1234).items()}
 def step():
     tr.run_generator_one_step(data); tr.run_discriminator_one_step(data)
 for _ in range(3): step()
-for rep in range(3):
+be.mg_set_option(10, 0)
+for rep in range(2):
     for ring in (3, 4):
         be.mg_set_option(9, ring)
         step(); torch.cuda.synchronize(); t0 = time.perf_counter()
