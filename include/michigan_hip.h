@@ -90,6 +90,8 @@ typedef struct mg_conv_desc {
     int32_t epilogue;
     int32_t act;
     float   slope;         /* LeakyReLU negative slope                        */
+    int32_t x_up;          /* SPADE: 1 = `x` is the [N][Hout/2][Wout/2][Cout] SOURCE of a nearest 2x upsample (generator.py:74,166-207):
+                              pixel (y, x) reads source pixel (y >> 1, x >> 1); the upsampled tensor is never materialised */
     int8_t  tap_dy[MG_MAX_TAPS];
     int8_t  tap_dx[MG_MAX_TAPS];
 } mg_conv_desc;
@@ -220,6 +222,26 @@ int mg_unpack_wgrad(const float* dw, float* d0, float* d1, int32_t cout, int32_t
  * workspace, out = 1 float); backward da = sign(a - b) * gscale[0] / numel (b is a constant). */
 int mg_l1_mean_fwd(const void* a, const void* b, int32_t dtype, int64_t numel, float* out, float* partial, void* stream);
 int mg_l1_mean_bwd(const void* a, const void* b, const float* gscale, int32_t dtype, int64_t numel, void* da, void* stream);
+
+/* Batch-norm input gradient for one or two consumers of the same x, optionally through a nearest 2x upsample of x
+ * (SPADE norm_0 + norm_s of a residual block with a learned shortcut, architecture.py:68-79; generator.py:166-207):
+ *   dx[p'] = sum_b sum_{q in quad(p')} rstd * (dh_b[q] * act_b'(h_b[q]) * g1_b[q] - s1_b - xhat[p'] * s2_b),   s1_b, s2_b = sums_b[0 / 1] * inv_count
+ * dh / h / g1: [P][C] at full resolution (h NULL when act is NONE, g1 NULL = 1); sums_b: the [2][C] raw (all-reduced) sums of
+ * mg_norm_bwd_reduce[_up].  up = 0: x, dx are [P][C] and quad(p') = {p'}; up = 1: x, dx are the [N][H/2][W/2][C] source /
+ * its gradient, P = N*H*W.  Geometry must satisfy mg_norm_apply2_supported(dtype, C).
+ * mg_norm_bwd_reduce_up = mg_norm_bwd_reduce (G = 1, P = N*H*W) with x given at half resolution. */
+typedef struct mg_norm_apply2_desc {
+    const void* dh[2]; const void* h[2]; const void* g1[2]; const float* sums[2];
+    const void* x; const float* mean; const float* rstd; void* dx;
+    int64_t P;
+    int32_t dtype, C, up, H, W;
+    int32_t act[2]; float slope[2]; float inv_count;
+} mg_norm_apply2_desc;
+int mg_norm_bwd_apply2(const mg_norm_apply2_desc* d, void* stream);
+int mg_norm_apply2_supported(int32_t dtype, int32_t C);
+int mg_norm_bwd_reduce_up(const void* dh, const void* h, const void* x, const void* g1, int32_t dtype, int32_t N, int32_t H, int32_t W,
+                          int32_t C, const float* mean, const float* rstd, int32_t act, float slope, void* dgb, float* sums,
+                          void* partial, void* stream);
 
 /* Batched weight preparation (one launch for any number of images; tables live in device memory).
  * mg_pack_job: mode 0 / 1 = mg_pack_weight's forward / data-gradient GEMM image of (w0[, w1]) in `dtype`, every element divided

@@ -29,7 +29,7 @@ class ConvDesc(ctypes.Structure):
         ("Hout", _i32), ("Wout", _i32), ("Cout", _i32), ("Cout_gemm", _i32), ("CoutP", _i32),
         ("Hj", _i32), ("Wj", _i32), ("isy", _i32), ("isx", _i32),
         ("osy", _i32), ("osx", _i32), ("ooy", _i32), ("oox", _i32),
-        ("ntaps", _i32), ("epilogue", _i32), ("act", _i32), ("slope", _f32),
+        ("ntaps", _i32), ("epilogue", _i32), ("act", _i32), ("slope", _f32), ("x_up", _i32),
         ("tap_dy", ctypes.c_int8 * MG_MAX_TAPS), ("tap_dx", ctypes.c_int8 * MG_MAX_TAPS),
     ]
 
@@ -53,6 +53,14 @@ class GradSlot(ctypes.Structure):
         ("cout", _i32), ("cin", _i32), ("taps", _i32), ("rows", _i32), ("cols", _i32), ("swapped", _i32),
         ("first_block", _i64),
     ]
+
+
+class NormApply2Desc(ctypes.Structure):
+    """struct mg_norm_apply2_desc (include/michigan_hip.h)."""
+    _fields_ = [("dh", _vp * 2), ("h", _vp * 2), ("g1", _vp * 2), ("sums", _vp * 2),
+                ("x", _vp), ("mean", _vp), ("rstd", _vp), ("dx", _vp), ("P", _i64),
+                ("dtype", _i32), ("C", _i32), ("up", _i32), ("H", _i32), ("W", _i32),
+                ("act", _i32 * 2), ("slope", _f32 * 2), ("inv_count", _f32)]
 
 
 class PackJob(ctypes.Structure):
@@ -79,6 +87,9 @@ _PROTOS = {
     "mg_norm_act_fwd": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _f32, _vp], _i32),
     "mg_norm_bwd_reduce": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp], _i32),
     "mg_norm_bwd_apply": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp], _i32),
+    "mg_norm_bwd_apply2": ([ctypes.POINTER(NormApply2Desc), _vp], _i32),
+    "mg_norm_apply2_supported": ([_i32, _i32], _i32),
+    "mg_norm_bwd_reduce_up": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp], _i32),
     "mg_act_bwd": ([_vp, _vp, _vp, _i32, _i64, _i32, _f32, _vp], _i32),
     "mg_upsample2x_fwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_upsample2x_bwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
@@ -129,7 +140,7 @@ _PROTOS = {
     "mg_last_error": ([], ctypes.c_char_p),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
-_NO_STATUS = {"mg_grad_slot_blocks", "mg_pack_job_blocks", "mg_sn_layer_blocks", "mg_stats_workspace", "mg_sizeof_desc", "mg_abi_version", "mg_last_error", "mg_noise_field_len", "mg_bicubic_ksize"}
+_NO_STATUS = {"mg_norm_apply2_supported", "mg_grad_slot_blocks", "mg_pack_job_blocks", "mg_sn_layer_blocks", "mg_stats_workspace", "mg_sizeof_desc", "mg_abi_version", "mg_last_error", "mg_noise_field_len", "mg_bicubic_ksize"}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmichigan_hip.so")
 
@@ -161,7 +172,7 @@ class HipBackend:
             raise RuntimeError("libmichigan_hip.so ABI version mismatch")
         if (self._lib.mg_sizeof_desc(0) != ctypes.sizeof(ConvDesc) or self._lib.mg_sizeof_desc(1) != ctypes.sizeof(WgradDesc)
                 or self._lib.mg_sizeof_desc(2) != ctypes.sizeof(GradSlot) or self._lib.mg_sizeof_desc(3) != ctypes.sizeof(PackJob)
-                or self._lib.mg_sizeof_desc(4) != ctypes.sizeof(SnLayer)):
+                or self._lib.mg_sizeof_desc(4) != ctypes.sizeof(SnLayer) or self._lib.mg_sizeof_desc(5) != ctypes.sizeof(NormApply2Desc)):
             raise RuntimeError("ctypes mirror of the descriptor structs is out of sync with include/michigan_hip.h")
 
     def __getattr__(self, fn):
@@ -170,7 +181,7 @@ class HipBackend:
         raw = getattr(self._lib, fn)
         if fn in _NO_STATUS:
             return raw
-        by_ref = fn in ("mg_conv_taps", "mg_conv_wgrad")
+        by_ref = fn in ("mg_conv_taps", "mg_conv_wgrad", "mg_norm_bwd_apply2")
 
         def call(*args):
             if by_ref:

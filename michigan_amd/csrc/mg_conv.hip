@@ -543,6 +543,9 @@ extern "C" int mg_conv_taps(const mg_conv_desc* d, void* stream)
     if (d->epilogue == MG_EPI_SPADE) {
         MG_CHECK_ARG(d->x && d->mean && d->rstd, "mg_conv_taps: SPADE epilogue needs x/mean/rstd");
         MG_CHECK_ARG(d->Cout_gemm == 2 * ((d->Cout + 31) / 32) * 32, "mg_conv_taps: SPADE needs Cout_gemm == 2*roundup(Cout,32)");
+        MG_CHECK_ARG(d->x_up == 0 || (d->x_up == 1 && (d->Hout % 2) == 0 && (d->Wout % 2) == 0 &&
+                                      (long)d->N * d->Hout * d->Wout * d->Cout < (1L << 32)),
+                     "mg_conv_taps: x_up needs even output sizes (and fewer than 2^32 elements)");
     } else {
         MG_CHECK_ARG(d->epilogue == MG_EPI_PLAIN, "mg_conv_taps: bad epilogue %d", d->epilogue);
         MG_CHECK_ARG(d->Cout <= d->Cout_gemm, "mg_conv_taps: Cout > Cout_gemm");
@@ -555,6 +558,7 @@ extern "C" int mg_conv_taps(const mg_conv_desc* d, void* stream)
     k.Hj = d->Hj; k.Wj = d->Wj; k.isy = d->isy; k.isx = d->isx;
     k.osy = d->osy; k.osx = d->osx; k.ooy = d->ooy; k.oox = d->oox;
     k.ntaps = d->ntaps; k.act = d->act; k.slope = d->slope;
+    k.x_up = d->epilogue == MG_EPI_SPADE ? d->x_up : 0;
     k.ngemm = d->N * d->Hj * d->Wj; k.tiles_m = 0; k.tpc = 1; k.tiles_y = k.tiles_x = 0;
     k.ksplit = 1; k.ntiles = 1; k.ws = nullptr;
     k.wide = ((g_mg_conv_wide && d->dtype == MG_BF16 && (d->Cout % 8) == 0) ? 1 : 0) | (g_mg_conv_dbg_noepi ? 2 : 0);

@@ -28,6 +28,7 @@ struct ConvK {              // kernel-side view of mg_conv_desc (passed by value
     int ksplit, ntiles;     // generic LDS-DMA kernel: split-K factor (1 = off) and tiles per K slice
     float* ws;              // split-K: fp32 partial sums [ksplit][ngemm][Cout_gemm]
     int wide;               // bf16 epilogue: lanes l and l+32 exchange quads so that every lane stores 16 contiguous bytes
+    int x_up;               // SPADE: x is the half-resolution source of a nearest 2x upsample (read at (y >> 1, x >> 1))
 };
 namespace {
 
@@ -154,10 +155,13 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
     const float neg = d.act == MG_ACT_NONE ? 1.f : (d.act == MG_ACT_RELU ? 0.f : d.slope);
     const bool relu = d.act == MG_ACT_RELU;
     size_t opix[NT];
+    unsigned xoff[NT];                 // SPADE: element offset of the pixel's x row (the half-resolution source when d.x_up)
     bool pok[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        pok[nt] = pixmap(wn * NT * 32 + nt * 32 + l31, opix[nt]);
+        size_t upix = 0;
+        pok[nt] = pixmap(wn * NT * 32 + nt * 32 + l31, opix[nt], upix);
+        if constexpr (EPI == MG_EPI_SPADE) xoff[nt] = pok[nt] ? (unsigned)((d.x_up ? upix : opix[nt]) * d.Cout) : 0u;
         opix[nt] = pok[nt] ? opix[nt] * d.Cout : 0;
     }
 
@@ -232,7 +236,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) xv[nt][q] = ET<T>::load4(X + opix[nt] + (oc[q] < d.Cout ? oc[q] : 0));
+                for (int q = 0; q < 2; ++q) xv[nt][q] = ET<T>::load4(X + xoff[nt] + (oc[q] < d.Cout ? oc[q] : 0));
             bool wide = false;
             if constexpr (sizeof(T) == 2) wide = (d.wide & 1) != 0;
             if (wide) {
@@ -301,8 +305,9 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
     }
 }
 
-// `pixmap(p, opix)`: p = pixel index inside the workgroup's pixel tile (0 .. TN-1) -> false if the pixel does
-// not exist, else opix = flat output pixel index ((n*Hout + oy)*Wout + ox).
+// `pixmap(p, opix, upix)`: p = pixel index inside the workgroup's pixel tile (0 .. TN-1) -> false if the pixel does
+// not exist, else opix = flat output pixel index ((n*Hout + oy)*Wout + ox) and upix = the index of pixel (oy >> 1, ox >> 1)
+// in a half-resolution [N][Hout/2][Wout/2] tensor (used when d.x_up).
 template <typename T, int MT, int NT, int EPI, int TM, typename PixMap>
 __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT][NT], int m0, PixMap&& pixmap,
                                               int wm, int wn, int l31, int hi, const float* par)
@@ -316,8 +321,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT
     // compile-time tile indices (static_for): runtime-indexed accumulator arrays would be demoted to scratch
     static_for<0, NT>([&](auto nt_) {
         constexpr int nt = decltype(nt_)::value;
-        size_t opix;
-        if (!pixmap(wn * NT * 32 + nt * 32 + l31, opix)) return;
+        size_t opix, upix = 0;
+        if (!pixmap(wn * NT * 32 + nt * 32 + l31, opix, upix)) return;
+        const size_t xo = (d.x_up ? upix : opix) * d.Cout;     // SPADE: where this pixel's x row starts
 
         if constexpr (EPI == MG_EPI_PLAIN) {
             const T* __restrict__ Res = reinterpret_cast<const T*>(d.resid);
@@ -377,7 +383,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT
                 }
                 const size_t o = opix * d.Cout + oc;
                 if ((d.Cout & 3) == 0) {
-                    const f32x4_t xv = ET<T>::load4(X + o);
+                    const f32x4_t xv = ET<T>::load4(X + xo + oc);
                     f32x4_t hv;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -390,7 +396,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (oc + j < d.Cout) {
-                            const float xh = (ET<T>::load1(X + o + j) - d.mean[oc + j]) * d.rstd[oc + j];
+                            const float xh = (ET<T>::load1(X + xo + oc + j) - d.mean[oc + j]) * d.rstd[oc + j];
                             ET<T>::store1(Out + o + j, mg_act(xh * g[j] + bt[j], d.act, d.slope));
                             if (G1) ET<T>::store1(G1 + o + j, g[j]);
                         }
@@ -458,12 +464,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // linear pixel tile of the tap-list kernels: q = q0 + p over N*Hj*Wj, strided/offset output grid
 struct LinearPixMap {
     const ConvK& d; int q0, HWj;
-    __device__ __forceinline__ bool operator()(int p, size_t& opix) const {
+    __device__ __forceinline__ bool operator()(int p, size_t& opix, size_t& upix) const {
         const int q = q0 + p;
         if (q >= d.ngemm) return false;
         const int n = q / HWj, r = q - n * HWj;
         const int jy = r / d.Wj, jx = r - jy * d.Wj;
-        opix = (size_t)((n * d.Hout + jy * d.osy + d.ooy) * d.Wout + jx * d.osx + d.oox);
+        const int oy = jy * d.osy + d.ooy, ox = jx * d.osx + d.oox;
+        opix = (size_t)((n * d.Hout + oy) * d.Wout + ox);
+        upix = (size_t)((n * (d.Hout >> 1) + (oy >> 1)) * (d.Wout >> 1) + (ox >> 1));
         return true;
     }
 };

@@ -298,11 +298,12 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
         }
     }
 
-    auto pixmap = [&](int p, size_t& opix) -> bool {
+    auto pixmap = [&](int p, size_t& opix, size_t& upix) -> bool {
         const int py = p >> 4;
         const int y = y0 + py, x = x0 + (((p & 15) - 2 * (py & 1)) & 15);
         if (y >= d.Hout || x >= d.Wout) return false;
         opix = (size_t)((img * d.Hout + y) * d.Wout + x);
+        upix = (size_t)((img * (d.Hout >> 1) + (y >> 1)) * (d.Wout >> 1) + (x >> 1));
         return true;
     };
     if (d.wide & 2) {                            // measurement aid (mg_set_option(10, 1)): main loop only; one store keeps the MFMAs alive

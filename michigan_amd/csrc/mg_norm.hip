@@ -39,7 +39,8 @@ template <typename T, int MODE, bool HAS_H = true>
 __global__ __launch_bounds__(NTHR) void reduce_stage1(
     const T* __restrict__ x, const T* __restrict__ dh, const T* __restrict__ h, const T* __restrict__ g1,
     const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dgb,
-    float* __restrict__ partial, int64_t P, int C, int tpr, int rpb, int64_t chunk, int act, float slope)
+    float* __restrict__ partial, int64_t P, int C, int tpr, int rpb, int64_t chunk, int act, float slope,
+    int up = 0, int H = 0, int W = 0)
 {
     __shared__ float red[NTHR * 8];
     const int tid = threadIdx.x;
@@ -65,7 +66,13 @@ __global__ __launch_bounds__(NTHR) void reduce_stage1(
         if (qv) {
             for (int64_t p = p0 + tr; p < p1; p += rpb) {
                 const size_t o = ((size_t)g * P + p) * C + c;
-                const f32x4_t xv = ET<T>::load4(x + o);
+                size_t ox = o;
+                if (MODE == 1 && up) {                       // x is the half-resolution source of a nearest 2x upsample (G == 1)
+                    const int pp = (int)p, n = pp / (H * W), rem = pp - n * (H * W);
+                    const int yy = rem / W, xx = rem - yy * W;
+                    ox = ((size_t)(n * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1)) * C + c;
+                }
+                const f32x4_t xv = ET<T>::load4(x + ox);
                 if (MODE == 0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { s[j] += xv[j]; ss[j] += xv[j] * xv[j]; }
@@ -393,9 +400,83 @@ __global__ void norm_finalize_kernel(const float* __restrict__ sums, int G, int 
 
 static inline int ew_grid(int64_t n) { int64_t b = (n + NTHR - 1) / NTHR; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
+// Input gradient of batch norm for up to TWO consumers that normalise the same x (SPADE norm_0 / norm_s of a block with a learned
+// shortcut, architecture.py:68-70,79), optionally through a nearest 2x upsample of x (generator.py:166-207):
+//   dx[src] = sum over branches b and over the (1 | 2x2) full-resolution pixels q of  rstd * (dxhat_b[q] - s1_b - xhat[src] * s2_b),
+//   dxhat_b = dh_b * act_b'(h_b) * g1_b,  s1_b / s2_b = sums_b[0 / 1] * inv_count.
+// One pass instead of two applies + autograd's add of their results + the upsample's 2x2 adjoint: x is read once at its own
+// resolution and dx written once at its own resolution.  Channel-resident threads like norm_bwd_apply_vec.
+template <typename T, int NB, bool UP>
+__global__ __launch_bounds__(NTHR) void norm_bwd_apply2_vec(const mg_norm_apply2_desc d, float neg0, float neg1)
+{
+    constexpr int VEC = VT<T>::VEC;
+    const int C = d.C, cv = C / VEC, rows = NTHR / cv;
+    const int tq = threadIdx.x % cv, tr = threadIdx.x / cv;
+    const int c = tq * VEC;
+    const T* dh0 = (const T*)d.dh[0]; const T* h0 = (const T*)d.h[0]; const T* g0 = (const T*)d.g1[0];
+    const T* dh1 = (const T*)d.dh[1]; const T* h1 = (const T*)d.h[1]; const T* g1 = (const T*)d.g1[1];
+    const T* x = (const T*)d.x; T* dx = (T*)d.dx;
+    constexpr int Q = UP ? 4 : 1;
+    float m[VEC], r[VEC], k1[VEC], k2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        m[j] = d.mean[c + j]; r[j] = d.rstd[c + j];
+        float s1 = d.sums[0][c + j], s2 = d.sums[0][C + c + j];
+        if (NB == 2) { s1 += d.sums[1][c + j]; s2 += d.sums[1][C + c + j]; }
+        k1[j] = (float)Q * r[j] * s1 * d.inv_count;
+        k2[j] = (float)Q * r[j] * r[j] * s2 * d.inv_count;
+    }
+    const int W = d.W, H = d.H, W2 = W >> 1, H2 = H >> 1;
+    const int64_t Pout = UP ? d.P / 4 : d.P;                       // pixels of x / dx
+    const int64_t step = (int64_t)gridDim.x * rows;
+    for (int64_t po = (int64_t)blockIdx.x * rows + tr; po < Pout; po += step) {
+        int64_t pf[Q];
+        if (UP) {
+            const int pp = (int)po, n = pp / (H2 * W2), rem = pp - n * (H2 * W2);
+            const int y2 = rem / W2, x2 = rem - y2 * W2;
+            const int64_t base = ((int64_t)n * H + 2 * y2) * W + 2 * x2;
+            pf[0] = base; if (Q > 1) { pf[1 % Q] = base + 1; pf[2 % Q] = base + W; pf[3 % Q] = base + W + 1; }
+        } else pf[0] = po;
+        float xv[VEC], acc[VEC];
+        VT<T>::load(x + (size_t)po * C + c, xv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const size_t o = (size_t)pf[q] * C + c;
+            float dv[VEC], hv[VEC], gv[VEC];
+            VT<T>::load(dh0 + o, dv);
+            if (h0) VT<T>::load(h0 + o, hv);
+            if (g0) VT<T>::load(g0 + o, gv);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float t = h0 ? dv[j] * act_factor(hv[j], neg0) : dv[j];
+                if (g0) t *= gv[j];
+                acc[j] += t;
+            }
+            if (NB == 2) {
+                VT<T>::load(dh1 + o, dv);
+                if (h1) VT<T>::load(h1 + o, hv);
+                if (g1) VT<T>::load(g1 + o, gv);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    float t = h1 ? dv[j] * act_factor(hv[j], neg1) : dv[j];
+                    if (g1) t *= gv[j];
+                    acc[j] += t;
+                }
+            }
+        }
+        float o4[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o4[j] = r[j] * acc[j] - k1[j] - k2[j] * (xv[j] - m[j]);
+        VT<T>::store(dx + (size_t)po * C + c, o4);
+    }
+}
+
 template <typename T, int MODE>
 int run_reduce(const void* x, const void* dh, const void* h, const void* g1, const float* mean, const float* rstd,
-               void* dgb, int G, int64_t P, int C, float* sums, void* partial, int act, float slope, hipStream_t st)
+               void* dgb, int G, int64_t P, int C, float* sums, void* partial, int act, float slope, hipStream_t st,
+               int up = 0, int H = 0, int W = 0)
 {
     const StatGeom sg = stat_geom(G, P, C);
     dim3 grid(sg.nchunks, G);
@@ -404,11 +485,11 @@ int run_reduce(const void* x, const void* dh, const void* h, const void* g1, con
     else if (MODE == 1 && h == nullptr)
         hipLaunchKernelGGL((reduce_stage1<T, MODE, false>), grid, dim3(NTHR), 0, st,
                            (const T*)x, (const T*)dh, (const T*)h, (const T*)g1, mean, rstd, (T*)dgb,
-                           (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, act, slope);
+                           (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, act, slope, up, H, W);
     else
         hipLaunchKernelGGL((reduce_stage1<T, MODE, true>), grid, dim3(NTHR), 0, st,
                            (const T*)x, (const T*)dh, (const T*)h, (const T*)g1, mean, rstd, (T*)dgb,
-                           (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, act, slope);
+                           (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, act, slope, up, H, W);
     MG_CHECK_LAUNCH("reduce_stage1");
     dim3 grid2((2 * C + 31) / 32, G);
     hipLaunchKernelGGL(reduce_stage2, grid2, dim3(256), 0, st, (const float*)partial, sums, sg.nchunks, 2 * C);
@@ -484,6 +565,63 @@ extern "C" int mg_norm_bwd_reduce(const void* dh, const void* h, const void* x, 
     if (dtype == MG_BF16)
         return run_reduce<uint16_t, 1>(x, dh, h, g1, mean, rstd, dgb, G, P, C, sums, partial, act, slope, st);
     return run_reduce<float, 1>(x, dh, h, g1, mean, rstd, dgb, G, P, C, sums, partial, act, slope, st);
+}
+
+extern "C" int mg_norm_bwd_reduce_up(const void* dh, const void* h, const void* x, const void* g1,
+                                     int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
+                                     const float* mean, const float* rstd, int32_t act, float slope,
+                                     void* dgb, float* sums, void* partial, void* stream)
+{
+    const int32_t G = 1; const int64_t P = (int64_t)N * H * W;
+    MG_CHECK_NORM_GEOM("mg_norm_bwd_reduce_up");
+    MG_CHECK_ARG(dh && (h || act == MG_ACT_NONE) && x && mean && rstd && sums && partial, "mg_norm_bwd_reduce_up: null pointer");
+    MG_CHECK_ARG(N > 0 && H > 0 && W > 0 && (H % 2) == 0 && (W % 2) == 0 && P < (1L << 31), "mg_norm_bwd_reduce_up: H, W must be even");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == MG_BF16)
+        return run_reduce<uint16_t, 1>(x, dh, h, g1, mean, rstd, dgb, G, P, C, sums, partial, act, slope, st, 1, H, W);
+    return run_reduce<float, 1>(x, dh, h, g1, mean, rstd, dgb, G, P, C, sums, partial, act, slope, st, 1, H, W);
+}
+
+template <typename T>
+static int launch_apply2(const mg_norm_apply2_desc& d, hipStream_t st)
+{
+    constexpr int VEC = VT<T>::VEC;
+    const int rows = NTHR / (d.C / VEC);
+    const bool two = d.dh[1] != nullptr;
+    const int64_t pout = d.up ? d.P / 4 : d.P;
+    auto neg = [](int act, float slope) { return act == MG_ACT_NONE ? 1.f : (act == MG_ACT_RELU ? 0.f : slope); };
+    const float n0 = neg(d.act[0], d.slope[0]), n1 = neg(d.act[1], d.slope[1]);
+    const dim3 grid(pix_grid(pout, rows, 1, 1)), blk(NTHR);
+    if (d.up) {
+        if (two) hipLaunchKernelGGL((norm_bwd_apply2_vec<T, 2, true>), grid, blk, 0, st, d, n0, n1);
+        else     hipLaunchKernelGGL((norm_bwd_apply2_vec<T, 1, true>), grid, blk, 0, st, d, n0, n1);
+    } else {
+        if (two) hipLaunchKernelGGL((norm_bwd_apply2_vec<T, 2, false>), grid, blk, 0, st, d, n0, n1);
+        else     hipLaunchKernelGGL((norm_bwd_apply2_vec<T, 1, false>), grid, blk, 0, st, d, n0, n1);
+    }
+    return 0;
+}
+
+extern "C" int mg_norm_apply2_supported(int32_t dtype, int32_t C)
+{
+    return dtype == MG_BF16 ? vec_geom_ok<uint16_t>(C) : (dtype == MG_F32 ? vec_geom_ok<float>(C) : 0);
+}
+
+extern "C" int mg_norm_bwd_apply2(const mg_norm_apply2_desc* d, void* stream)
+{
+    MG_CHECK_ARG(d != nullptr, "mg_norm_bwd_apply2: null descriptor");
+    MG_CHECK_ARG(d->dtype == MG_F32 || d->dtype == MG_BF16, "mg_norm_bwd_apply2: bad dtype");
+    MG_CHECK_ARG(d->dh[0] && d->sums[0] && d->x && d->mean && d->rstd && d->dx, "mg_norm_bwd_apply2: null pointer");
+    MG_CHECK_ARG((d->dh[1] == nullptr) == (d->sums[1] == nullptr), "mg_norm_bwd_apply2: the second branch needs dh and sums");
+    for (int b = 0; b < 2; ++b)
+        MG_CHECK_ARG(d->act[b] != MG_ACT_TANH && (d->h[b] || d->act[b] == MG_ACT_NONE || !d->dh[b]), "mg_norm_bwd_apply2: activation needs its output h");
+    MG_CHECK_ARG(d->C > 0 && d->P > 0 && d->P < (1L << 31) && mg_norm_apply2_supported(d->dtype, d->C), "mg_norm_bwd_apply2: unsupported geometry C=%d", d->C);
+    MG_CHECK_ARG(!d->up || (d->H > 0 && d->W > 0 && (d->H % 2) == 0 && (d->W % 2) == 0 && d->P % ((int64_t)d->H * d->W) == 0),
+                 "mg_norm_bwd_apply2: up needs even H, W and P = N*H*W");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == MG_BF16) launch_apply2<uint16_t>(*d, st); else launch_apply2<float>(*d, st);
+    MG_CHECK_LAUNCH("mg_norm_bwd_apply2");
+    return MG_OK;
 }
 
 extern "C" int mg_norm_bwd_apply(const void* dh, const void* h, const void* x, const void* g1,

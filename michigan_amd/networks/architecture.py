@@ -8,7 +8,9 @@ from .spectral import spectral_norm
 
 from .. import ops
 from .layers import FusedReLU, HipConv2d
-from .normalization import SPADE
+from .normalization import SPADE, spade_pair
+
+PAIR_FUSED = __import__("os").environ.get("MG_NO_PAIR") != "1"          # A/B switch (MG_NO_PAIR=1): norm_0 / norm_s of a learned-shortcut block as one autograd node, upsample by index map
 
 
 class SPADEResnetBlock(nn.Module):
@@ -41,7 +43,15 @@ class SPADEResnetBlock(nn.Module):
         if self.learned_shortcut:
             self.norm_s = SPADE(cfg, fin, label_nc)
 
-    def forward(self, x, seg):
+    def forward(self, x, seg, up=False):
+        """up=True: the block consumes the nearest 2x upsample of x (generator.py:166-207).  With a learned shortcut and in
+        training mode the upsampled tensor is never built: norm_0 / norm_s read x through the index map (spade_pair)."""
+        if self.learned_shortcut and self.training and PAIR_FUSED and ops.spade_pair_supported(x):
+            h0, hs = spade_pair(self.norm_0, self.norm_s, x, seg, (ops.ACT_LRELU, ops.ACT_NONE), up=up)
+            dx = self.conv_0(h0)
+            return self.conv_1(self.norm_1(dx, seg, act=ops.ACT_LRELU), resid=self.conv_s(hs))
+        if up:
+            x = ops.upsample2x(x)
         h0, stats = self.norm_0(x, seg, act=ops.ACT_LRELU, return_stats=True)
         shared = stats if self.training else None          # norm_s normalises the same x: reuse the reduction
         x_s = self.conv_s(self.norm_s(x, seg, stats=shared)) if self.learned_shortcut else x

@@ -80,12 +80,10 @@ class SPADEBGenerator(BaseNetwork):
         hair_masks = [F.interpolate(hair, size=(int(hh / d), int(hw / d)), mode="nearest") for d in (8, 4, 2)] + [hair]
 
         x = self.head_0(x, pyramid)
-        x = self.G_middle_0(ops.upsample2x(x), pyramid)
-        if opt.num_upsampling_layers == "more":
-            x = ops.upsample2x(x)
-        x = self.G_middle_1(x, pyramid)
+        x = self.G_middle_0(x, pyramid, up=True)
+        x = self.G_middle_1(x, pyramid, up=opt.num_upsampling_layers == "more")
         for i, block in enumerate((self.up_0, self.up_1, self.up_2, self.up_3)):
-            x = block(ops.upsample2x(x), pyramid)
+            x = block(x, pyramid, up=True)            # the 2x nearest upsample is folded into the block's first SPADE layers
             last = i == 3
             if opt.bf_direct_add:
                 x = back_feats[i] + x

@@ -70,6 +70,26 @@ class SPADE(nn.Module):
         return (out, st) if return_stats else out
 
 
+def spade_pair(norm_a: SPADE, norm_b: SPADE, x, segmap, acts, up: bool = False):
+    """norm_a(x) and norm_b(x) (optionally of the nearest 2x upsample of x, never materialised) with ONE statistics reduction
+    and one autograd node -- SPADEResnetBlock's norm_0 / norm_s (architecture.py:68-70,79).  Returns (h_a, h_b)."""
+    n, hs, ws, c = x.shape
+    h, w = (2 * hs, 2 * ws) if up else (hs, ws)
+    seg = segmap.at(h, w) if isinstance(segmap, SegPyramid) else SegPyramid(segmap, x.dtype).at(h, w)
+    bn_a, bn_b = norm_a.param_free_norm, norm_b.param_free_norm
+    if bn_a.training:
+        pending = ops.batch_stats_begin(x, up=up)                          # sums + async all-reduce (data parallel)
+        actv_a = norm_a.mlp_shared[0](seg, act=ops.ACT_RELU)               # independent of the statistics: overlap with it
+        actv_b = norm_b.mlp_shared[0](seg, act=ops.ACT_RELU)
+        mean, rstd, count, sums = ops.batch_stats_finish(pending, bn_a.eps, bn_a.momentum, bn_a.running_mean, bn_a.running_var)
+        with torch.no_grad():
+            ops.advance_running_stats(sums, count, bn_b.eps, bn_b.momentum, bn_b.running_mean, bn_b.running_var)
+    else:
+        raise RuntimeError("spade_pair: training mode only (in eval mode each layer normalises with its own running statistics)")
+    mods = tuple((a, m.mlp_gamma.weight, m.mlp_gamma.bias, m.mlp_beta.weight, m.mlp_beta.bias) for a, m in ((actv_a, norm_a), (actv_b, norm_b)))
+    return ops.spade_modulate_pair(x, mods, mean, rstd, count, acts=acts, slope=0.2, up=up)
+
+
 class _ConvNorm(nn.Sequential):
     """conv -> instance norm with the following LeakyReLU fused into the norm kernel."""
 

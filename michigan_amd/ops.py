@@ -104,7 +104,7 @@ def pad_channels(x: torch.Tensor, mult: int = 8) -> torch.Tensor:
 # ----------------------------------------------------------------------------
 def _launch_conv(inp, wt, out, bias, taps, *, Hj, Wj, isy, isx, osy=1, osx=1, ooy=0, oox=0,
                  cout, cout_gemm, act=ACT_NONE, slope=0.2, resid=None,
-                 spade_x=None, mean=None, rstd=None, gamma_out=None, algo_cin=None, relu_mask=None):
+                 spade_x=None, mean=None, rstd=None, gamma_out=None, algo_cin=None, relu_mask=None, x_up=False):
     d = C.ConvDesc()
     d.in_, d.wt, d.out = inp.data_ptr(), wt.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
@@ -121,6 +121,7 @@ def _launch_conv(inp, wt, out, bias, taps, *, Hj, Wj, isy, isx, osy=1, osx=1, oo
     d.osy, d.osx, d.ooy, d.oox = osy, osx, ooy, oox
     d.epilogue = C.MG_EPI_SPADE if spade_x is not None else C.MG_EPI_PLAIN
     d.act, d.slope = act, slope
+    d.x_up = 1 if (x_up and spade_x is not None) else 0
     _set_taps(d, taps)
     assert wt.shape[0] == len(taps) and wt.shape[2] == inp.shape[3] and wt.dtype == inp.dtype
     C.backend().mg_conv_taps(d, _stream(inp))
@@ -553,16 +554,19 @@ def conv_transpose2d_infer(x: torch.Tensor, weight: torch.Tensor, bias: Optional
 # ----------------------------------------------------------------------------
 # batch statistics (sync-BN) and SPADE modulation
 # ----------------------------------------------------------------------------
-def batch_stats_begin(x: torch.Tensor):
+def batch_stats_begin(x: torch.Tensor, up: bool = False):
     """First half of batch_stats: local channel sums and, when data parallel, the all-reduce of the 2C sums launched
     ASYNCHRONOUSLY -- the caller runs work that does not need the statistics (SPADE's mlp_shared conv) before
-    batch_stats_finish, so the latency-bound collective overlaps with it.  Returns an opaque pending tuple."""
+    batch_stats_finish, so the latency-bound collective overlaps with it.  Returns an opaque pending tuple.
+    up=True: the statistics of the nearest 2x upsample of x (every value occurs four times), which is never materialised."""
     with torch.no_grad():
         x = _nhwc(x)
         c = x.shape[-1]
-        count = x.numel() // c
+        count = x.numel() // c * (4 if up else 1)
         src = getattr(x, "_mg_stats_src", None) if STATS_FROM_UPSAMPLE_SOURCE else None
-        if src is not None and src.shape[-1] == c and 4 * src.numel() == x.numel():
+        if up:
+            sums = channel_sums(x).mul_(4.0)
+        elif src is not None and src.shape[-1] == c and 4 * src.numel() == x.numel():
             # x = nearest 2x upsample of src (upsample2x): every source value occurs exactly four times, so
             # sum(x) = 4 sum(src) and sum(x^2) = 4 sum(src^2) -- reduce the quarter-size tensor (x4 is exact in fp32)
             sums = channel_sums(src).mul_(4.0)
@@ -711,6 +715,125 @@ class _SpadeFn(torch.autograd.Function):
             db = db.reshape(rows // 64, 2, 32)
             dbg, dbb = db[:, 0].reshape(-1)[:c], db[:, 1].reshape(-1)[:c]
         return dx, dactv, dwg, dbg, dwb, dbb, None, None, None, None, None, None, None
+
+
+class _SpadePairFn(torch.autograd.Function):
+    """Two SPADE modulations of the SAME x with shared batch statistics -- norm_0 (+LeakyReLU) and norm_s of a residual block
+    with a learned shortcut (architecture.py:68-70,79) -- as one autograd node, so that the backward pass makes ONE pass for
+    dx (mg_norm_bwd_apply2: both branches' terms and, when x entered through a nearest 2x upsample, the 2x2 adjoint) instead of
+    two applies + autograd's add + the upsample's backward, and ONE sync-BN all-reduce for the pair.  `up`: x is the
+    half-resolution source; the fused convs read it at (y >> 1, x >> 1) and the upsampled tensor never exists."""
+
+    @staticmethod
+    def forward(ctx, x, actv0, wg0, bg0, wb0, bb0, actv1, wg1, bg1, wb1, bb1, mean, rstd, count, act0, act1, slope, up, relu0, relu1, sinks):
+        x, actv0, actv1 = _nhwc(x), _nhwc(actv0), _nhwc(actv1)
+        n, hs, ws, c = x.shape
+        h, w = (2 * hs, 2 * ws) if up else (hs, ws)
+        if actv0.shape[:3] != (n, h, w) or actv1.shape[:3] != (n, h, w) or actv0.dtype != x.dtype or actv1.dtype != x.dtype:
+            raise ValueError("spade_modulate_pair: activation maps and x disagree in shape / dtype")
+        rows = 2 * _roundup(c, 32)
+        need = any(ctx.needs_input_grad)
+        outs, g1s = [], []
+        for actv, wg, bg, wb, bb, act in ((actv0, wg0, bg0, wb0, bb0, act0), (actv1, wg1, bg1, wb1, bb1, act1)):
+            if wg.shape != wb.shape or wg.shape[0] != c or wg.shape[1] != actv.shape[3]:
+                raise ValueError("spade_modulate_pair: mlp_gamma / mlp_beta weights have the wrong shape")
+            kh = wg.shape[2]
+            wp = pack_weight(wg, wb, x.dtype, _roundup(rows, 128), actv.shape[3], 0)
+            bias = _interleave32(bg.detach().float(), bb.detach().float()).contiguous()
+            out = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
+            g1 = torch.empty_like(out) if need else None
+            _launch_conv(actv, wp, out, bias, fwd_taps(kh, kh, kh // 2), Hj=h, Wj=w, isy=1, isx=1, cout=c, cout_gemm=rows,
+                         act=act, slope=slope, spade_x=x, mean=mean, rstd=rstd, gamma_out=g1, x_up=up)
+            outs.append(out)
+            g1s.append(g1)
+        if need:
+            ctx.save_for_backward(x, actv0, wg0, wb0, outs[0], g1s[0], actv1, wg1, wb1, outs[1], g1s[1], mean, rstd)
+        ctx.cfg = (count, (act0, act1), slope, bool(up), (bool(relu0), bool(relu1)), sinks, (h, w))
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, dh0, dh1):
+        x, actv0, wg0, wb0, h0, g10, actv1, wg1, wb1, h1, g11, mean, rstd = ctx.saved_tensors
+        count, acts, slope, up, relus, sinks, (hh, ww) = ctx.cfg
+        n, _, _, c = x.shape
+        p = n * hh * ww
+        rows = 2 * _roundup(c, 32)
+        be = C.backend()
+        need_x = ctx.needs_input_grad[0]
+        sums = torch.empty((2, 2, c), dtype=torch.float32, device=x.device)          # [branch][sum dxhat | sum dxhat * xhat][C]
+        branches = ((dh0.contiguous(), h0, g10, actv0, wg0, wb0, 1), (dh1.contiguous(), h1, g11, actv1, wg1, wb1, 6))
+        dgbs = []
+        for b, (dh, h, g1, actv, wg, wb, base) in enumerate(branches):
+            alloc = torch.zeros if rows != 2 * c else torch.empty                      # padded gamma/beta rows must read 0
+            dgb = alloc((n, hh, ww, rows), dtype=x.dtype, device=x.device)
+            ws = torch.empty(max(int(be.mg_stats_workspace(1, p, c)), 4), dtype=torch.uint8, device=x.device)
+            hp = _p(h) if acts[b] != ACT_NONE else None
+            if up:
+                be.mg_norm_bwd_reduce_up(_p(dh), hp, _p(x), _p(g1), _dt(x), n, hh, ww, c, _p(mean), _p(rstd), acts[b], slope,
+                                         _p(dgb), _p(sums[b]), _p(ws), _stream(x))
+            else:
+                be.mg_norm_bwd_reduce(_p(dh), hp, _p(x), _p(g1), _dt(x), 1, p, c, _p(mean), _p(rstd), acts[b], slope,
+                                      _p(dgb), _p(sums[b]), _p(ws), _stream(x))
+            dgbs.append(dgb)
+        work = None
+        if need_x and SYNC_BN_GROUP is not None:
+            import torch.distributed as dist
+            work = dist.all_reduce(sums, group=SYNC_BN_GROUP, async_op=True)         # both branches in ONE collective; overlaps with the convs below
+            _count_collective("syncbn_bwd")
+        grads = [None] * 11
+        for b, (dh, h, g1, actv, wg, wb, base) in enumerate(branches):
+            kh = wg.shape[2]
+            pad = kh // 2
+            if ctx.needs_input_grad[base]:
+                wt = pack_weight(wg, wb, x.dtype, _roundup(actv.shape[3], 128), rows, 1)
+                grads[base] = conv_dgrad(dgbs[b], wt, kh, kh, 1, pad, (hh, ww), actv.shape[3],
+                                         relu_mask=actv if (relus[b] and FUSE_RELU_MASK) else None)
+            need_w = ctx.needs_input_grad[base + 1] or ctx.needs_input_grad[base + 3]
+            need_b = ctx.needs_input_grad[base + 2] or ctx.needs_input_grad[base + 4]
+            sink, slot, db = sinks[b], None, None
+            if sink is not None and need_w and ctx.needs_input_grad[base + 1] and ctx.needs_input_grad[base + 3]:
+                slot = sink[0].grad_slot(wg, wb, sink[2] if need_b else None, sink[3] if need_b else None, kh * kh, rows, actv.shape[3], None)
+            if slot is not None:
+                conv_wgrad(actv, dgbs[b], kh, kh, 1, pad, want_bias=need_b, out=(slot[1], slot[2]))
+                sink[0].slot_written(slot[0])
+            elif need_w:
+                res = conv_wgrad(actv, dgbs[b], kh, kh, 1, pad, want_bias=need_b)
+                grads[base + 1], grads[base + 3] = unpack_wgrad(res[0] if need_b else res, wg.shape, two=True)
+                db = res[1] if need_b else None
+            elif need_b:
+                db = channel_sums(dgbs[b])[0, 0]
+            if db is not None:
+                db = db.reshape(rows // 64, 2, 32)
+                grads[base + 2], grads[base + 4] = db[:, 0].reshape(-1)[:c], db[:, 1].reshape(-1)[:c]
+        if need_x:
+            if work is not None:
+                work.wait()
+            d = C.NormApply2Desc()
+            for b, (dh, h, g1, *_r) in enumerate(branches):
+                d.dh[b], d.g1[b], d.sums[b] = dh.data_ptr(), g1.data_ptr(), sums[b].data_ptr()
+                d.h[b] = h.data_ptr() if acts[b] != ACT_NONE else None
+                d.act[b], d.slope[b] = acts[b], slope
+            d.x, d.mean, d.rstd = x.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+            dx = torch.empty_like(x)
+            d.dx, d.P, d.dtype, d.C = dx.data_ptr(), p, _dt(x), c
+            d.up, d.H, d.W, d.inv_count = (1 if up else 0), hh, ww, 1.0 / float(count)
+            be.mg_norm_bwd_apply2(d, _stream(x))
+            grads[0] = dx
+        return tuple(grads) + (None,) * 10
+
+
+def spade_pair_supported(x: torch.Tensor) -> bool:
+    return bool(C.backend().mg_norm_apply2_supported(_dt(x), x.shape[-1])) and x.numel() * 4 < (1 << 32)
+
+
+def spade_modulate_pair(x, mods, mean, rstd, count, *, acts, slope=0.2, up=False):
+    """(h0, h1) = the two SPADE modulations `mods` = ((actv, w_gamma, b_gamma, w_beta, b_beta), ...) of the same x (or of its
+    nearest 2x upsample when `up`), one fused conv launch each, ONE autograd node (see _SpadePairFn)."""
+    (a0, wg0, bg0, wb0, bb0), (a1, wg1, bg1, wb1, bb1) = mods
+    sk0, sk1 = _sink_for(wg0, bg0, wb0, bb0), _sink_for(wg1, bg1, wb1, bb1)
+    sinks = (None if sk0 is None else (sk0[0], sk0[1], bg0, bb0), None if sk1 is None else (sk1[0], sk1[1], bg1, bb1))
+    return _SpadePairFn.apply(x, a0, wg0, bg0, wb0, bb0, a1, wg1, bg1, wb1, bb1, mean, rstd, count, acts[0], acts[1], slope, bool(up),
+                              getattr(a0, "_mg_relu_out", False), getattr(a1, "_mg_relu_out", False), sinks)
 
 
 def spade_modulate(x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, *, act=ACT_NONE, slope=0.2):

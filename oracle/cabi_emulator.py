@@ -86,7 +86,7 @@ class EmulatorBackend:
 
     def mg_sizeof_desc(self, which):
         from michigan_amd import _cabi
-        return ctypes.sizeof((_cabi.ConvDesc, _cabi.WgradDesc, _cabi.GradSlot, _cabi.PackJob, _cabi.SnLayer)[which])
+        return ctypes.sizeof((_cabi.ConvDesc, _cabi.WgradDesc, _cabi.GradSlot, _cabi.PackJob, _cabi.SnLayer, _cabi.NormApply2Desc)[which])
 
     def mg_last_error(self):
         return b""
@@ -119,7 +119,11 @@ class EmulatorBackend:
             rg = 64 * (ch // 32) + ch % 32
             g1 = 1.0 + acc[..., rg]
             beta = acc[..., rg + 32]
-            xs = _view(d.x, (d.N, d.Hout, d.Wout, c), td).double()[:, oy, ox]
+            if d.x_up:                                       # x given as the half-resolution source of a nearest 2x upsample
+                src = _view(d.x, (d.N, d.Hout // 2, d.Wout // 2, c), td).double()
+                xs = src.repeat_interleave(2, 1).repeat_interleave(2, 2)[:, oy, ox]
+            else:
+                xs = _view(d.x, (d.N, d.Hout, d.Wout, c), td).double()[:, oy, ox]
             mean = _view(d.mean, (c,), torch.float32).double()
             rstd = _view(d.rstd, (c,), torch.float32).double()
             pre = (xs - mean) * rstd * g1 + beta
@@ -197,6 +201,45 @@ class EmulatorBackend:
             rg = 64 * (ch // 32) + ch % 32
             out[:, rg] = (dpre[0] * xh[0]).to(td)
             out[:, rg + 32] = dpre[0].to(td)
+        return 0
+
+    def mg_norm_bwd_reduce_up(self, dh, h, x, g1, dtype, N, H, W, C, mean, rstd, act, slope, dgb, sums, partial, stream=None):
+        td = _TD[dtype]
+        xf = _view(x, (N, H // 2, W // 2, C), td).repeat_interleave(2, 1).repeat_interleave(2, 2).contiguous()
+        return self.mg_norm_bwd_reduce(dh, h, xf.data_ptr(), g1, dtype, 1, N * H * W, C, mean, rstd, act, slope, dgb, sums, partial)
+
+    def mg_norm_apply2_supported(self, dtype, C):
+        vec = 8 if dtype == MG_BF16 else 4
+        return int(C % vec == 0 and C // vec <= 256 and 256 % (C // vec) == 0)
+
+    def mg_norm_bwd_apply2(self, d, stream=None):
+        """Contract of mg_norm_bwd_apply2 (include/michigan_hip.h): float64, one rounding."""
+        td, C, P = _TD[d.dtype], d.C, d.P
+        if d.up:
+            n = P // (d.H * d.W)
+            xs = _view(d.x, (n, d.H // 2, d.W // 2, C), td).double()
+            xfull = xs.repeat_interleave(2, 1).repeat_interleave(2, 2).reshape(P, C)
+        else:
+            xfull = _view(d.x, (P, C), td).double()
+        mean = _view(d.mean, (C,), torch.float32).double()
+        rs = _view(d.rstd, (C,), torch.float32).double()
+        xh = (xfull - mean) * rs
+        total = torch.zeros((P, C), dtype=torch.float64)
+        for b in range(2):
+            if not d.dh[b]:
+                continue
+            dxh = _view(d.dh[b], (P, C), td).double()
+            if d.h[b]:
+                dxh = dxh * _act_grad_from_out(_view(d.h[b], (P, C), td).double(), d.act[b], d.slope[b])
+            if d.g1[b]:
+                dxh = dxh * _view(d.g1[b], (P, C), td).double()
+            sums = _view(d.sums[b], (2, C), torch.float32).double() * float(d.inv_count)
+            total += rs * (dxh - sums[0] - xh * sums[1])
+        if d.up:
+            total = total.view(n, d.H // 2, 2, d.W // 2, 2, C).sum((2, 4))
+            _view(d.dx, (n, d.H // 2, d.W // 2, C), td)[:] = total.to(td)
+        else:
+            _view(d.dx, (P, C), td)[:] = total.to(td)
         return 0
 
     def mg_norm_bwd_apply(self, dh, h, x, g1, dtype, G, P, C, mean, rstd, s1, s2, act, slope, dx, stream=None):

@@ -791,3 +791,46 @@ def test_batched_spectral_norm_and_pack_match_contract(dt):
     _close(f"batched weights {dt}: u", hip[4], ref[4], 1e-4 if dt == "f32" else 5e-3)
     _close(f"batched weights {dt}: v", hip[5], ref[5], 1e-4 if dt == "f32" else 5e-3)
     assert ((hip[6].cpu() - ref[6]).abs() > 2.5e-3).float().mean() < 0.01       # Adam (lr 1e-3): sign-like updates, see trainer_parity.compare
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("up", [False, True])
+def test_spade_pair_with_folded_upsample(dt, up):
+    """spade_modulate_pair (two SPADE modulations of one x as one autograd node; `up`: x read through the nearest-2x index map by
+    the fused conv epilogue, mg_norm_bwd_reduce_up and mg_norm_bwd_apply2) on the HIP kernels vs the contract emulator, and
+    against the unfused composition upsample2x -> spade_modulate x 2 (autograd adds the two dx, up2 adjoint) on the same device."""
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(41)
+    n, hs, ws, c, ca = 2, 18, 22, 64, 128
+    h, w = (2 * hs, 2 * ws) if up else (hs, ws)
+    x = torch.randn(n, hs, ws, c, generator=g).to(DT[dt]).requires_grad_()
+    a0 = torch.randn(n, h, w, ca, generator=g).clamp_min(0).to(DT[dt]).requires_grad_()
+    a1 = torch.randn(n, h, w, ca, generator=g).clamp_min(0).to(DT[dt]).requires_grad_()
+    ws_ = [torch.randn(c, ca, 3, 3, generator=g).mul_(0.03).requires_grad_() for _ in range(4)]
+    bs_ = [torch.randn(c, generator=g).mul_(0.1).requires_grad_() for _ in range(4)]
+    gy0 = torch.randn(n, h, w, c, generator=g).to(DT[dt])
+    gy1 = torch.randn(n, h, w, c, generator=g).to(DT[dt])
+
+    def run(fused):
+        def fn(x, a0, a1, w0, w1, w2, w3, b0, b1, b2, b3, gy0, gy1):
+            src = x
+            mean, rstd, count, _ = ops.batch_stats_finish(ops.batch_stats_begin(src.detach(), up=up))
+            if fused:
+                h0, h1 = ops.spade_modulate_pair(src, ((a0, w0, b0, w1, b1), (a1, w2, b2, w3, b3)), mean, rstd, count,
+                                                 acts=(ops.ACT_LRELU, ops.ACT_NONE), up=up)
+            else:
+                xf = ops.upsample2x(src) if up else src
+                h0 = ops.spade_modulate(xf, a0, w0, b0, w1, b1, mean, rstd, count, act=ops.ACT_LRELU)
+                h1 = ops.spade_modulate(xf, a1, w2, b2, w3, b3, mean, rstd, count, act=ops.ACT_NONE)
+            loss = (h0.float() * gy0.float()).sum() + (h1.float() * gy1.float()).sum()
+            grads = torch.autograd.grad(loss, [x, a0, a1, w0, w1, w2, w3, b0, b1, b2, b3])
+            return [h0, h1] + list(grads)
+        return _both(fn, (x, a0, a1, *ws_, *bs_, gy0, gy1))
+    (hip_f, _), (emu_f, _) = run(True)
+    (hip_u, _), (emu_u, _) = run(False)
+    names = ["h0", "h1", "dx", "dactv0", "dactv1", "dwg0", "dwb0", "dwg1", "dwb1", "dbg0", "dbb0", "dbg1", "dbb1"]
+    tol = {"f32": 5e-5, "bf16": 2.0 ** -6}[dt]
+    for i, nm in enumerate(names):
+        _close(f"pair {dt} up={up} {nm}: hip vs emulator", hip_f[i], emu_f[i], tol)
+        _close(f"pair {dt} up={up} {nm}: fused vs unfused (emulator)", emu_f[i], emu_u[i], 1e-6 if dt == "f32" else 2.0 ** -6)
+        _close(f"pair {dt} up={up} {nm}: fused vs unfused (hip)", hip_f[i], hip_u[i], tol * (4 if nm == "dx" and dt == "bf16" else 1))

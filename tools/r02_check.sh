@@ -13,6 +13,7 @@ if [ -z "$QUICK" ]; then
   MG_BENCH_BACKEND=gloo timeout 400 python bench.py --gpus 2 --steps 2 --warmup 1 --batch-per-gpu 2 --no-cpu-baseline > $OUT/bench_gloo2.json 2> $OUT/bench_gloo2.err; echo "bench_gloo2 rc=$?" | tee -a $OUT/rc.log
   timeout 300 python bench.py --batch-per-gpu 4 --no-cpu-baseline > $OUT/bench_bs4.json 2> $OUT/bench_bs4.err; echo "bench_bs4 rc=$?" | tee -a $OUT/rc.log
   MG_LEGACY_WEIGHTS=1 timeout 300 python bench.py --no-cpu-baseline > $OUT/bench_legacy_weights.json 2> $OUT/bench_legacy_weights.err; echo "bench_legacy rc=$?" | tee -a $OUT/rc.log
+  MG_NO_PAIR=1 timeout 300 python bench.py --no-cpu-baseline > $OUT/bench_nopair.json 2> $OUT/bench_nopair.err; echo "bench_nopair rc=$?" | tee -a $OUT/rc.log
   timeout 300 python bench.py --no-cpu-baseline > $OUT/bench_again.json 2> $OUT/bench_again.err; echo "bench_again rc=$?" | tee -a $OUT/rc.log
   timeout 300 python tools/conv_census.py > $OUT/conv_census.txt 2> $OUT/conv_census.err; echo "census rc=$?" | tee -a $OUT/rc.log
 fi
