@@ -99,13 +99,6 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
         const int q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
-    if constexpr (NT == 4) {
-        // experiment (mg_set_option(11, n)): the second workgroup that lands on each CU starts late, so that the epilogue of one
-        // falls into the main loop of the other instead of both leaving the matrix pipe idle together
-        const int stag = d.wide >> 8;
-        if (stag && ((blockIdx.x >> 8) & 1) && blockIdx.x < 512)
-            for (int i = 0; i < stag; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     const int tm = tile % d.tiles_m;  tile /= d.tiles_m;
     const int tx = tile % d.tiles_x;  tile /= d.tiles_x;
     const int ty = tile % d.tiles_y;
