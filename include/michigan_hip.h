@@ -279,7 +279,7 @@ int64_t mg_sn_layer_blocks(int32_t rows, int32_t cols, int32_t which);
  *       += (gemm[..] - s * u[co] * v[ci*taps + t]) / sigma[0]     spectral norm (w_sn != NULL), s = sum(gemm * w_sn)
  *   dbias0/1[co] += dbias_gemm[row(co)]
  * `swapped`: the GEMM image is [t][ci][row] (weight gradient computed with the operand roles exchanged).
- * `s` = one zero-initialised double per spectral-normed slot.  The table lives in device memory; `first_block` = running sum
+ * `s` = one double per spectral-normed slot (written here: per-workgroup partials summed in a fixed order -> deterministic).  The table lives in device memory; `first_block` = running sum
  * of mg_grad_slot_blocks over the preceding slots and block_slot[b] = slot that owns workgroup b (host-built). */
 typedef struct mg_grad_slot {
     float* gemm; float* dbias_gemm;
@@ -289,7 +289,7 @@ typedef struct mg_grad_slot {
     int64_t first_block;
 } mg_grad_slot;
 int     mg_grad_drain(const mg_grad_slot* table_dev, int32_t nslots, const int32_t* block_slot_dev, int32_t nblocks,
-                      int32_t has_sn, void* stream);
+                      double* partial, void* stream);    /* partial: nblocks doubles of scratch, or NULL when no slot has w_sn */
 int64_t mg_grad_slot_blocks(int32_t cout, int32_t cin, int32_t ntens);        /* workgroups slot needs (host helper) */
 
 /* Hinge GAN loss on a patch discriminator's 1-channel logit map with the wide-edge weight mask (loss.py:60-140).

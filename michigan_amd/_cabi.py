@@ -109,7 +109,7 @@ _PROTOS = {
     "mg_pack_job_blocks": ([_i32, _i32, _i32, _i32, _i32, _i32], _i64),
     "mg_sn_power_iteration": ([_vp, _i32, _vp, _i32, _vp, _i32, _i32, _f32, _vp], _i32),
     "mg_sn_layer_blocks": ([_i32, _i32, _i32], _i64),
-    "mg_grad_drain": ([_vp, _i32, _vp, _i32, _i32, _vp], _i32),
+    "mg_grad_drain": ([_vp, _i32, _vp, _i32, _vp, _vp], _i32),
     "mg_grad_slot_blocks": ([_i32, _i32, _i32], _i64),
     "mg_wide_edge_weight": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp], _i32),
     "mg_hinge_fwd": ([_vp, _vp, _i32, _i64, _i32, _vp, _vp], _i32),

@@ -5,8 +5,9 @@
 // + the sigma-backward kernel, and autograd then added the result into the flat gradient arena: ~375 launches of
 // 5-10 us per training step (fills 95, unpack 74, dot + sn_bwd 48, adds 158; 2.9 ms of a 75 ms step, rocprofv3
 // profiles/r02a_kernel_stats.csv).  Now the wgrad kernels accumulate straight into a persistent GEMM-order arena that
-// stays resident (optim.FlatAdam.gemm) and TWO launches per optimiser step move everything:
-//   grad_sn_dot_kernel   spectral-normed slots only:  s = sum(g * W_sn)  (fp64 atomics of per-tile partials)
+// stays resident (optim.FlatAdam.gemm) and two (three with spectral norm) launches per optimiser step move everything:
+//   grad_sn_dot_kernel   spectral-normed slots only:  per-tile partials of s = sum(g * W_sn); grad_sn_finish_kernel adds them in a
+//                        fixed order (bit-identical on every rank of a data-parallel job)
 //   grad_drain_kernel    every slot:  dst[co][ci][t] += SN ? (g - s u[co] v[ci*T+t]) / sigma : g ;  gemm <- 0 ;  biases
 // (reference: torch.autograd of nn.Conv2d weights + torch.nn.utils.spectral_norm, architecture.py:31-42,
 //  normalization.py:28-29,94-99; optimiser arenas pix2pix_model.py:137-145).
@@ -62,13 +63,14 @@ __device__ __forceinline__ void load_tile(const mg_grad_slot& s, int which, int 
     }
 }
 
-__global__ __launch_bounds__(256) void grad_sn_dot_kernel(const mg_grad_slot* __restrict__ tab, const int32_t* __restrict__ block_slot)
+__global__ __launch_bounds__(256) void grad_sn_dot_kernel(const mg_grad_slot* __restrict__ tab, const int32_t* __restrict__ block_slot,
+                                                          double* __restrict__ partial)
 {
     __shared__ float lds[64 * (MAXT + 1)];
     __shared__ double red[4];
     const Tile tl = decode(tab, block_slot, blockIdx.x);
     const mg_grad_slot& s = tab[tl.slot];
-    if (tl.bias || !s.w_sn) return;
+    if (tl.bias || !s.w_sn) { if (threadIdx.x == 0) partial[blockIdx.x] = 0.0; return; }
     const int T = s.taps, pitch = T | 1;
     const int ncol = min(64, s.cin - tl.ci0), run = ncol * T;
     // element e of the contiguous run <-> (column c = e / T, tap t = e % T), walked without divisions in the loop
@@ -92,7 +94,24 @@ __global__ __launch_bounds__(256) void grad_sn_dot_kernel(const mg_grad_slot* __
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(s.s, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// s[slot] = sum of the slot's per-workgroup partials in a FIXED order (one workgroup per slot): the value every rank of a
+// data-parallel job computes from the same all-reduced gradients must be bit-identical, or the replicas' weights drift apart
+__global__ __launch_bounds__(256) void grad_sn_finish_kernel(const mg_grad_slot* __restrict__ tab, const double* __restrict__ partial, int nblocks_total,
+                                                             const int32_t* __restrict__ block_slot)
+{
+    __shared__ double red[256];
+    const mg_grad_slot& s = tab[blockIdx.x];
+    if (!s.w_sn) return;
+    const int b0 = (int)s.first_block;
+    double acc = 0.0;
+    for (int b = b0 + threadIdx.x; b < nblocks_total && block_slot[b] == (int)blockIdx.x; b += 256) acc += partial[b];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) *s.s = red[0];
 }
 
 __global__ __launch_bounds__(256) void grad_drain_kernel(const mg_grad_slot* __restrict__ tab, const int32_t* __restrict__ block_slot)
@@ -140,13 +159,15 @@ __global__ __launch_bounds__(256) void grad_drain_kernel(const mg_grad_slot* __r
 }  // namespace
 
 extern "C" int mg_grad_drain(const mg_grad_slot* table_dev, int32_t nslots, const int32_t* block_slot_dev, int32_t nblocks,
-                             int32_t has_sn, void* stream)
+                             double* partial, void* stream)
 {
     MG_CHECK_ARG(table_dev && block_slot_dev && nslots > 0 && nblocks > 0, "mg_grad_drain: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (has_sn) {
-        hipLaunchKernelGGL(grad_sn_dot_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, table_dev, block_slot_dev);
+    if (partial) {                                   // spectral-normed slots present: their dot products first
+        hipLaunchKernelGGL(grad_sn_dot_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, table_dev, block_slot_dev, partial);
         MG_CHECK_LAUNCH("mg_grad_drain(sn dot)");
+        hipLaunchKernelGGL(grad_sn_finish_kernel, dim3((unsigned)nslots), dim3(256), 0, st, table_dev, (const double*)partial, nblocks, block_slot_dev);
+        MG_CHECK_LAUNCH("mg_grad_drain(sn finish)");
     }
     hipLaunchKernelGGL(grad_drain_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, table_dev, block_slot_dev);
     MG_CHECK_LAUNCH("mg_grad_drain");

@@ -236,7 +236,8 @@ class FlatAdam:
             self._table_event.synchronize()                     # last step's upload of the table has long finished
         tab = (C.GradSlot * len(self._slot_list)).from_address(self._table_host.data_ptr())
         nsn = sum(1 for s in self._slot_list if s.written and s.sn is not None)
-        sdot = torch.zeros(max(nsn, 1), dtype=torch.float64, device=self.flat.device)
+        nblk = int(self._block_slot_dev.numel())
+        sdot = torch.empty(max(nsn, 1) + (nblk if nsn else 0), dtype=torch.float64, device=self.flat.device)   # s per SN slot, then per-workgroup partials
         gp, fp, k = self.gemm.data_ptr(), self.flat_grad.data_ptr(), 0
         gaddr = lambda p: fp + 4 * self._span_of[id(p)][0]
         for s, e in zip(self._slot_list, tab):
@@ -261,8 +262,8 @@ class FlatAdam:
             self._table_event.record()
             stream = ctypes.c_void_p(torch.cuda.current_stream(self.flat.device).cuda_stream)
         C.backend().mg_grad_drain(ctypes.c_void_p(self._table_dev.data_ptr()), len(self._slot_list),
-                                  ctypes.c_void_p(self._block_slot_dev.data_ptr()), int(self._block_slot_dev.numel()),
-                                  1 if nsn else 0, stream)
+                                  ctypes.c_void_p(self._block_slot_dev.data_ptr()), nblk,
+                                  ctypes.c_void_p(sdot.data_ptr() + 8 * max(nsn, 1)) if nsn else None, stream)
         self._reset_step_state()
 
     # ---- overlapped gradient averaging ----------------------------------------------

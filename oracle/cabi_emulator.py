@@ -446,7 +446,7 @@ class EmulatorBackend:
     def mg_grad_slot_blocks(self, cout, cin, ntens):
         return ntens * ((cin + 63) // 64) * ((cout + 3) // 4) + 1
 
-    def mg_grad_drain(self, table, nslots, block_slot, nblocks, has_sn, stream=None):
+    def mg_grad_drain(self, table, nslots, block_slot, nblocks, partial, stream=None):
         """Contract of include/michigan_hip.h `mg_grad_drain`, slot by slot (float64 arithmetic, one rounding)."""
         from michigan_amd import _cabi
         slots = (_cabi.GradSlot * nslots).from_address(_addr(table))
