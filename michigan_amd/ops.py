@@ -213,39 +213,47 @@ def block_map(counts, device) -> torch.Tensor:
 
 def _repack_arena(arena):
     """Re-pack every cached GEMM image whose source parameters live in `arena` with one batched launch (in place: the
-    images keep their addresses) and stamp them with the parameters' current state."""
+    images keep their addresses) and stamp them with the parameters' current state.  The table holds only weak references
+    to the parameters (they reference the arena, which must be able to die)."""
     ent = _ARENA_PACK_TABLES.get(id(arena))
-    if ent is None or ent[0]() is not arena:
+    if ent is not None and (ent[0]() is not arena or any(r0() is None or (r1 is not None and r1() is None) for _, r0, r1, _ in ent[1])):
+        ent = None
+    if ent is None:
+        for k in [k for k, v in _ARENA_PACK_TABLES.items() if v[0]() is None]:
+            del _ARENA_PACK_TABLES[k]
         slots = []
         for key, (state, r0, r1, dst) in _PACK_CACHE.items():
             w0, w1 = r0(), (r1() if r1 is not None else None)
             if w0 is None or getattr(w0, "_mg_arena", None) is not arena or (r1 is not None and w1 is None):
                 continue
-            slots.append((key, w0, w1, dst))
+            if w0.shape[2] * w0.shape[3] <= 49:
+                slots.append((key, r0, r1, dst))
         if not slots:
             return
         be = C.backend()
-        slots = [sl for sl in slots if sl[1].shape[2] * sl[1].shape[3] <= 49]
-        if not slots:
-            return
-        counts = [int(be.mg_pack_job_blocks(key[5], w0.shape[0], w0.shape[1], w0.shape[2] * w0.shape[3], key[3], key[4]))
-                  for key, w0, _, _ in slots]
-        table = DeviceTable(C.PackJob, len(slots), slots[0][3].device)
+        dev = slots[0][3].device
+        counts = []
+        table = DeviceTable(C.PackJob, len(slots), dev)
         first = 0
-        for row, (key, w0, w1, dst), nb in zip(table.begin_update(), slots, counts):
+        for row, (key, r0, r1, dst) in zip(table.begin_update(), slots):
+            w0, w1 = r0(), (r1() if r1 is not None else None)
             _, _, dtype, rows_p, cols_p, mode = key
+            taps = w0.shape[2] * w0.shape[3]
+            nb = int(be.mg_pack_job_blocks(mode, w0.shape[0], w0.shape[1], taps, rows_p, cols_p))
             row.w0, row.w1, row.dst, row.sigma = w0.data_ptr(), (w1.data_ptr() if w1 is not None else None), dst.data_ptr(), None
             row.dtype = C.MG_BF16 if dtype == torch.bfloat16 else C.MG_F32
-            row.cout, row.cin, row.taps = w0.shape[0], w0.shape[1], w0.shape[2] * w0.shape[3]
+            row.cout, row.cin, row.taps = w0.shape[0], w0.shape[1], taps
             row.rows_p, row.cols_p, row.mode, row.first_block = rows_p, cols_p, mode, first
+            counts.append(nb)
             first += nb
-        ent = (weakref.ref(arena), slots, table, block_map(counts, slots[0][3].device), first, table.upload())
+        ent = (weakref.ref(arena), slots, table, block_map(counts, dev), first, table.upload())
         _ARENA_PACK_TABLES[id(arena)] = ent
     _, slots, table, bmap, nblocks, tab_ptr = ent
     C.backend().mg_pack_weights(tab_ptr, len(slots), _p(bmap), nblocks, _stream(bmap))
-    for key, w0, w1, dst in slots:
+    for key, r0, r1, dst in slots:
+        w0, w1 = r0(), (r1() if r1 is not None else None)
         state = (w0._version, 0 if w1 is None else w1._version, _arena_epoch(w0), 0 if w1 is None else _arena_epoch(w1))
-        _PACK_CACHE[key] = (state, weakref.ref(w0), None if w1 is None else weakref.ref(w1), dst)
+        _PACK_CACHE[key] = (state, r0, r1, dst)
 
 
 _PACK_CACHE = {}
