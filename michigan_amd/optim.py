@@ -110,6 +110,7 @@ class FlatAdam:
         self.exp_avg.copy_(m.to(self.exp_avg.device))
         self.exp_avg_sq.copy_(v.to(self.exp_avg.device))
         self.weight_epoch += 1
+        ops._ARENA_PACK_TABLES.pop(id(self), None)              # its job table points into the old parameter storage
         self.gemm, self._slots, self._slot_list, self._gemm_used, self._layout_dirty = None, {}, [], 0, True
         self._table_host = self._table_dev = self._block_slot_dev = None
 
