@@ -174,17 +174,27 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
             f32x4_t bias4[4];
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) bias4[rq] = *reinterpret_cast<const f32x4_t*>(par + lr + rq * 8);
-            static_for<0, NT>([&](auto nt_) {
-                constexpr int nt = decltype(nt_)::value;
-                f32x4_t rv[4], mk[4];
-                if (Res) {
+            // residual / ReLU-mask quads of ALL column tiles of this row tile are requested before the first use (one memory round
+            // trip per 32 rows instead of one per 32x32 tile).  A launch has a residual (forward) or a mask (data gradient), not
+            // both; the rare both-case keeps the mask loads at their use.
+            const T* __restrict__ Aux = Res ? Res : Msk;
+            f32x4_t aux[NT][4];
+            if (Aux) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
                         const int co = m0 + lr + rq * 8;
-                        rv[rq] = ET<T>::load4(Res + opix[nt] + (co < d.Cout ? co : 0));
+                        aux[nt][rq] = ET<T>::load4(Aux + opix[nt] + (co < d.Cout ? co : 0));
                     }
-                }
-                if (Msk) {
+            }
+            const bool both = Res && Msk;
+            static_for<0, NT>([&](auto nt_) {
+                constexpr int nt = decltype(nt_)::value;
+                f32x4_t rv[4], mk[4];
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) { rv[rq] = aux[nt][rq]; mk[rq] = aux[nt][rq]; }
+                if (both) {
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
                         const int co = m0 + lr + rq * 8;
@@ -227,6 +237,19 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
         const T* __restrict__ X = reinterpret_cast<const T*>(d.x);
         T* __restrict__ G1 = reinterpret_cast<T*>(d.gamma_out);
         const int lrow = wm * 64;                    // first GEMM row of this wave's [gamma|beta] block in the tile
+        // all x quads of both halves are requested before the first one is used: ONE memory round trip per tile instead of two
+        // (the main loop's operand-address and fragment registers are dead here, so the 16 quads fit; on the K = 1152 layers the
+        // epilogue is 18-22 % of the launch, profiles/r02_halo_ring_ab.txt)
+        f32x4_t xall[2][NT][2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int occ = ((m0 + lrow) >> 1) + (hh * 2 + q) * 8 + hi * 4;
+                    xall[hh][nt][q] = ET<T>::load4(X + xoff[nt] + (occ < d.Cout ? occ : 0));
+                }
         static_for<0, 2>([&](auto h_) {
             constexpr int h = decltype(h_)::value;
             int oc[2];
@@ -236,7 +259,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) xv[nt][q] = ET<T>::load4(X + xoff[nt] + (oc[q] < d.Cout ? oc[q] : 0));
+                for (int q = 0; q < 2; ++q) xv[nt][q] = xall[h][nt][q];
             bool wide = false;
             if constexpr (sizeof(T) == 2) wide = (d.wide & 1) != 0;
             if (wide) {
