@@ -34,9 +34,10 @@ for name, cin, cout, hw, spade in SHAPES:
         be.mg_set_option(11, 1); same = torch.equal(fn(), ref_out); be.mg_set_option(11, 0)
         print("   persistent == one-tile-per-workgroup launch, bitwise:", same, flush=True)
         for rep in range(2):
-            for ring in (3, 4, 13):               # 13 = ring 3 without the epilogue (mg_set_option(10, 1)): main-loop time alone
+            for ring in (3, 4, 13, 23):           # 13 = ring 3 without the epilogue (mg_set_option(10, 1)); 23 = ring 3, persistent workgroups
                 be.mg_set_option(9, 4 if ring == 4 else 3)
                 be.mg_set_option(10, 1 if ring == 13 else 0)
+                be.mg_set_option(11, 1 if ring == 23 else 0)
                 for _ in range(3): fn()
                 torch.cuda.synchronize()
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
