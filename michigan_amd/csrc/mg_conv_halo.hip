@@ -32,7 +32,6 @@
 #endif
 
 extern int g_mg_conv_halo_big;     // mg_set_option(4, v): 0 = never use the 128 x 16x16 geometry
-extern int g_mg_conv_halo_persist; // mg_set_option(11, v): 1 = persistent workgroups for the 128 x 16x16 geometry
 extern int g_mg_conv_halo_ring;    // mg_set_option(9, v): weight-slab ring depth of the 128 x 16x16 geometry (3 or 4)
 
 namespace {
@@ -94,14 +93,9 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    // Persistent form (d.halo_tiles > gridDim.x, mg_set_option(11, 1)): a workgroup walks tiles b, b + gridDim.x, ... (gridDim.x is a
-    // multiple of 8, so it stays on its XCD and the tile <-> XCD map is the one-tile-per-workgroup launch's).  Between tiles only a
-    // barrier: every wave is done with the LDS image (the epilogue's parameter reads included) before the next tile's DMA lands.
-    for (int vb = blockIdx.x; vb < d.halo_tiles; vb += gridDim.x) {
-    if (vb != (int)blockIdx.x) __builtin_amdgcn_s_barrier();
     int tile;
     {
-        const int nblk = d.halo_tiles, b = vb;
+        const int nblk = gridDim.x, b = blockIdx.x;
         const int q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
@@ -314,10 +308,9 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
     };
     if (d.wide & 2) {                            // measurement aid (mg_set_option(10, 1)): main loop only; one store keeps the MFMAs alive
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<T*>(d.out)[0] = (T)1;
-        continue;
+        return;
     }
     conv_epilogue<T, MT, NT, EPI, TM_H>(d, acc, m0, pixmap, wm, wn, l31, hi, par);
-    }   // tiles of this workgroup
 }
 
 template <typename T, int EPI, int WM, int NT, int RING = 3>
@@ -327,10 +320,8 @@ int launch_halo_g(ConvK& k, hipStream_t st)
     k.tiles_m = (k.Cout_gemm + G::TM - 1) / G::TM;
     k.tiles_y = (k.Hin + G::TH - 1) / G::TH;
     k.tiles_x = (k.Win + TW - 1) / TW;
-    long nblk = (long)k.N * k.tiles_y * k.tiles_x * k.tiles_m;
+    const long nblk = (long)k.N * k.tiles_y * k.tiles_x * k.tiles_m;
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_taps(halo): bad grid %ld", nblk);
-    k.halo_tiles = (int)nblk;
-    if (NT == 4 && g_mg_conv_halo_persist && nblk > 512) nblk = 512;       // two resident workgroups per CU x 256 CUs, each walks nblk / 512 tiles
     static_assert(RING == 3 || 2 * G::LDS <= 160 * 1024, "LDS budget of the deep ring: two workgroups per CU");
     auto kern = conv3x3_halo_kernel<T, EPI, WM, NT, RING>;
     if constexpr (G::LDS > 65536) {
