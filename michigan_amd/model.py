@@ -25,9 +25,6 @@ from . import inputs, networks, parallel
 from .optim import FlatAdam
 
 
-VGG_TARGET_ASYNC = __import__("os").environ.get("MG_VGG_ASYNC", "1") == "1"      # real-image VGG taps on a side stream (A/B: MG_VGG_ASYNC=0)
-
-
 def default_options(**over) -> argparse.Namespace:
     """Option namespace = options/base_options.py + train_options.py defaults + the README training flags."""
     d = dict(
@@ -195,9 +192,6 @@ class Pix2PixModel(nn.Module):
         losses = {}
         d = self._maybe_inpaint(d)
         pending = self._ref_is_tag_async(d)
-        y_feats = None
-        if VGG_TARGET_ASYNC and self.opt.curr_step == 1 and not self.opt.no_vgg_loss and not getattr(self.opt, "remove_background", False):
-            y_feats = self.criterionVGG.target_features_async(d["image_tag"])     # overlaps with the generator forward below
         fake = self.generate_fake(d)
         pred_fake, pred_real = self.discriminate(d, fake)
         label = d["input_tag"][:, 1:2]
@@ -208,7 +202,7 @@ class Pix2PixModel(nn.Module):
             if not self.opt.no_ganFeat_loss:
                 losses["GAN_Feat"] = self.criterionGANFeat(pred_fake, pred_real, label)
             if not self.opt.no_vgg_loss:
-                losses["VGG"] = self.criterionVGG(fake, d["image_tag"], label, y_feats=y_feats) * self.opt.lambda_vgg
+                losses["VGG"] = self.criterionVGG(fake, d["image_tag"], label) * self.opt.lambda_vgg
         if not getattr(self.opt, "no_orient_loss", True):
             orient, conf = self.criterionOrient(fake, d["orient"], d["input_tag"])
             losses["ORIENT"] = orient * self.opt.lambda_orient

@@ -130,37 +130,14 @@ class VGGLoss(nn.Module):
             self.vgg = self.vgg.cuda()
         self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
         self.opt = opt
-        self._side = None
 
     def L1_loss_mask(self, input, target, label):
         lab = F.interpolate(label, size=input.shape[2:], mode="nearest")
         return F.l1_loss(input * lab, target * lab, reduction="sum") / (lab.sum() * input.shape[1] + 1e-5)
 
-    def target_features_async(self, y):
-        """The (constant) real image's VGG taps on a SIDE HIP stream, to be started before the generator runs: the tower's
-        full-resolution kernels fill the CUs that the generator's encoder / 8x8 ... 64x64 layers leave idle.  Returns a handle
-        for forward(..., y_feats=handle); the consumer stream waits for the side stream only where the features are used."""
-        if not y.is_cuda:
-            with torch.no_grad():
-                return (self.vgg(y), None)
-        main = torch.cuda.current_stream(y.device)
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=y.device)
-        self._side.wait_stream(main)                         # y (and the weights) are ready on the main stream
-        with torch.cuda.stream(self._side), torch.no_grad():
-            feats = self.vgg(y)
-        for t in feats:
-            t.record_stream(main)                            # freed on the main stream's timeline, not the side stream's
-        return (feats, self._side)
-
-    def forward(self, x, y, label=None, y_feats=None):
-        if y_feats is not None:
-            y_feats, side = y_feats
-            if side is not None:
-                torch.cuda.current_stream(x.device).wait_stream(side)
-        else:
-            with torch.no_grad():
-                y_feats = self.vgg(y)
+    def forward(self, x, y, label=None):
+        with torch.no_grad():
+            y_feats = self.vgg(y)
         x_feats = self.vgg(x)
         loss = 0
         for w, a, b in zip(self.weights, x_feats, y_feats):
