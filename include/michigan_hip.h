@@ -158,9 +158,9 @@ int mg_norm_act_fwd(const void* x, void* y, int32_t dtype, int32_t G, int64_t P,
  *     sums[g][0][c] = sum_p dxhat ; sums[g][1][c] = sum_p dxhat * xhat
  *     if dgb != NULL (SPADE): writes d[gamma|beta] in GEMM row order
  *     ([P][2*roundup(C,32)]): dgamma = dpre * xhat, dbeta = dpre.
- * mg_norm_bwd_apply:  dx = rstd * (dxhat - s1[g][c] - xhat * s2[g][c])
- *     with s1 = sum_dxhat / n, s2 = sum_dxhat_xhat / n supplied by the host
- *     (after the cross-rank all-reduce for sync-BN).
+ * mg_norm_bwd_apply:  dx = rstd * (dxhat - S1[g][c] - xhat * S2[g][c]),  S1 = s1[g * sum_gstride + c] * sum_scale (S2 alike):
+ *     the raw sums of mg_norm_bwd_reduce (s1 = sums, s2 = sums + C, sum_gstride = 2C, sum_scale = 1 / n) after the
+ *     cross-rank all-reduce for sync-BN, or pre-divided per-group vectors (sum_gstride = C, sum_scale = 1).
  * Replaces autograd of normalization.py:105-116 + F.batch_norm / InstanceNorm.  h (the activation's output) is
  * read only for its sign and may be NULL when act == MG_ACT_NONE.
  * ------------------------------------------------------------------------- */
@@ -171,7 +171,7 @@ int mg_norm_bwd_reduce(const void* dh, const void* h, const void* x, const void*
 int mg_norm_bwd_apply(const void* dh, const void* h, const void* x, const void* g1,
                       int32_t dtype, int32_t G, int64_t P, int32_t C,
                       const float* mean, const float* rstd, const float* s1, const float* s2,
-                      int32_t act, float slope, void* dx, void* stream);
+                      int32_t sum_gstride, float sum_scale, int32_t act, float slope, void* dx, void* stream);
 
 /* dpre = dy * act'(y) for the activations fused in conv epilogues
  * (ReLU: architecture.py:163-178, MaskGAN_networks.py:145; LeakyReLU:
@@ -196,7 +196,14 @@ int mg_avgpool3s2_bwd(const void* dy, void* dx, int32_t dtype, int32_t N, int32_
 /* nn.MaxPool2d(2, 2) of the VGG tower (architecture.py:163-178); backward
  * routes dy to the first maximal element of each 2x2 window (ATen order). */
 int mg_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
-int mg_maxpool2_bwd(const void* dy, const void* x, void* dx, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int mg_maxpool2_bwd(const void* dy, const void* x, void* dx, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C,
+                    int32_t relu_input, void* stream);   /* relu_input = 1: x is a ReLU's output; the routed gradient is also multiplied by (x > 0) */
+/* out [N][HW][8] (dtype) = per pixel [ planar[n][0..cp)[p] (fp32 NCHW) | nhwc[p][0..cf) (dtype, pixel pitch cs) | zeros ]:
+ * an 8-channel NHWC network input assembled from the reference's planar maps and an NHWC image in one pass */
+int mg_assemble_nhwc8(const float* planar, int32_t cp, const void* nhwc, int32_t cs, int32_t cf, void* out, int32_t dtype,
+                      int32_t N, int64_t HW, void* stream);
+/* out = (g1 + g2) * act'(y) (g2 may be NULL): gradient of an activation output with two consumers, in one pass */
+int mg_grad_sum_act(const void* g1, const void* g2, const void* y, void* out, int32_t dtype, int64_t numel, int32_t act, float slope, void* stream);
 
 /* background blend  y = act(bg * (1 - hair[p]) + x * (1 - back[p]))
  * (generator.py:186,197,208,219; act = LeakyReLU after the last block, generator.py:227); hair/back are

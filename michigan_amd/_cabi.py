@@ -86,7 +86,7 @@ _PROTOS = {
     "mg_norm_finalize": ([_vp, _i32, _i32, ctypes.c_double, _f32, _f32, _vp, _vp, _vp, _vp, _vp], _i32),
     "mg_norm_act_fwd": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _f32, _vp], _i32),
     "mg_norm_bwd_reduce": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp], _i32),
-    "mg_norm_bwd_apply": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp], _i32),
+    "mg_norm_bwd_apply": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _i32, _f32, _vp, _vp], _i32),
     "mg_norm_bwd_apply2": ([ctypes.POINTER(NormApply2Desc), _vp], _i32),
     "mg_norm_apply2_supported": ([_i32, _i32], _i32),
     "mg_norm_bwd_reduce_up": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp], _i32),
@@ -98,7 +98,9 @@ _PROTOS = {
     "mg_avgpool3s2_fwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_avgpool3s2_bwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_maxpool2_fwd": ([_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
-    "mg_maxpool2_bwd": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "mg_maxpool2_bwd": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "mg_assemble_nhwc8": ([_vp, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _i64, _vp], _i32),
+    "mg_grad_sum_act": ([_vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _vp], _i32),
     "mg_blend_fwd": ([_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _vp], _i32),
     "mg_blend_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _f32, _vp], _i32),
     "mg_pack_weight": ([_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp], _i32),

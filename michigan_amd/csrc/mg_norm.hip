@@ -164,14 +164,14 @@ template <typename T>
 __global__ void norm_bwd_apply_kernel(const T* __restrict__ dh, const T* __restrict__ h, const T* __restrict__ x,
                                       const T* __restrict__ g1, T* __restrict__ dx, int64_t nquads, int64_t P, int C,
                                       const float* __restrict__ mean, const float* __restrict__ rstd,
-                                      const float* __restrict__ s1, const float* __restrict__ s2, int act, float slope)
+                                      const float* __restrict__ s1, const float* __restrict__ s2, int sgs, float sscale, int act, float slope)
 {
     const int c4 = C / 4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * blockDim.x) {
         const int qd = (int)(i % c4);
         const int64_t pix = i / c4;
         const int g = (int)(pix / P);
-        const size_t sc = (size_t)g * C + qd * 4;
+        const size_t sc = (size_t)g * C + qd * 4, ss = (size_t)g * sgs + qd * 4;
         const f32x4_t dv = ET<T>::load4(dh + i * 4);
         f32x4_t hv = {1.f, 1.f, 1.f, 1.f};
         if (h) hv = ET<T>::load4(h + i * 4);
@@ -184,7 +184,7 @@ __global__ void norm_bwd_apply_kernel(const T* __restrict__ dh, const T* __restr
             const float r = rstd[sc + j];
             const float xh = (xv[j] - mean[sc + j]) * r;
             const float dxh = dv[j] * mg_act_grad_from_out(hv[j], act, slope) * gv[j];
-            o[j] = r * (dxh - s1[sc + j] - xh * s2[sc + j]);
+            o[j] = r * (dxh - s1[ss + j] * sscale - xh * (s2[ss + j] * sscale));
         }
         ET<T>::store4(dx + i * 4, o);
     }
@@ -242,7 +242,7 @@ template <typename T, int PIX>
 __global__ __launch_bounds__(NTHR) void norm_bwd_apply_vec(const T* __restrict__ dh, const T* __restrict__ h, const T* __restrict__ x,
                                                          const T* __restrict__ g1, T* __restrict__ dx, int64_t P, int C,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                         const float* __restrict__ s1, const float* __restrict__ s2, float neg)
+                                                         const float* __restrict__ s1, const float* __restrict__ s2, int sgs, float sscale, float neg)
 {
     constexpr int VEC = VT<T>::VEC;
     const int cv = C / VEC, rows = NTHR / cv;
@@ -251,8 +251,8 @@ __global__ __launch_bounds__(NTHR) void norm_bwd_apply_vec(const T* __restrict__
     float m[VEC], r[VEC], c1[VEC], c2[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        const size_t i = (size_t)g * C + c + j;
-        m[j] = mean[i]; r[j] = rstd[i]; c1[j] = r[j] * s1[i]; c2[j] = r[j] * r[j] * s2[i];
+        const size_t i = (size_t)g * C + c + j, k = (size_t)g * sgs + c + j;
+        m[j] = mean[i]; r[j] = rstd[i]; c1[j] = r[j] * (s1[k] * sscale); c2[j] = r[j] * r[j] * (s2[k] * sscale);
     }
     const size_t base = (size_t)g * P * C + c;
     const int64_t step = (int64_t)gridDim.x * rows;
@@ -627,9 +627,11 @@ extern "C" int mg_norm_bwd_apply2(const mg_norm_apply2_desc* d, void* stream)
 extern "C" int mg_norm_bwd_apply(const void* dh, const void* h, const void* x, const void* g1,
                                  int32_t dtype, int32_t G, int64_t P, int32_t C,
                                  const float* mean, const float* rstd, const float* s1, const float* s2,
-                                 int32_t act, float slope, void* dx, void* stream)
+                                 int32_t sum_gstride, float sum_scale, int32_t act, float slope, void* dx, void* stream)
 {
     MG_CHECK_NORM_GEOM("mg_norm_bwd_apply");
+    MG_CHECK_ARG(sum_gstride >= C, "mg_norm_bwd_apply: sum_gstride < C");
+    const int sgs = sum_gstride; const float sscale = sum_scale;
     MG_CHECK_ARG(dh && (h || act == MG_ACT_NONE) && x && mean && rstd && s1 && s2 && dx, "mg_norm_bwd_apply: null pointer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t nq = (int64_t)G * P * (C / 4);
@@ -639,12 +641,12 @@ extern "C" int mg_norm_bwd_apply(const void* dh, const void* h, const void* x, c
             const int rows = NTHR / (C / 8);
             hipLaunchKernelGGL((norm_bwd_apply_vec<uint16_t, 2>), dim3(pix_grid(P, rows, 2, G), G), dim3(NTHR), 0, st,
                                (const uint16_t*)dh, (const uint16_t*)h, (const uint16_t*)x, (const uint16_t*)g1, (uint16_t*)dx,
-                               P, C, mean, rstd, s1, s2, neg);
+                               P, C, mean, rstd, s1, s2, sgs, sscale, neg);
         } else {
             const int rows = NTHR / (C / 4);
             hipLaunchKernelGGL((norm_bwd_apply_vec<float, 2>), dim3(pix_grid(P, rows, 2, G), G), dim3(NTHR), 0, st,
                                (const float*)dh, (const float*)h, (const float*)x, (const float*)g1, (float*)dx,
-                               P, C, mean, rstd, s1, s2, neg);
+                               P, C, mean, rstd, s1, s2, sgs, sscale, neg);
         }
         MG_CHECK_LAUNCH("mg_norm_bwd_apply");
         return MG_OK;
@@ -652,11 +654,11 @@ extern "C" int mg_norm_bwd_apply(const void* dh, const void* h, const void* x, c
     if (dtype == MG_BF16)
         hipLaunchKernelGGL(norm_bwd_apply_kernel<uint16_t>, dim3(ew_grid(nq)), dim3(NTHR), 0, st,
                            (const uint16_t*)dh, (const uint16_t*)h, (const uint16_t*)x, (const uint16_t*)g1, (uint16_t*)dx,
-                           nq, P, C, mean, rstd, s1, s2, act, slope);
+                           nq, P, C, mean, rstd, s1, s2, sgs, sscale, act, slope);
     else
         hipLaunchKernelGGL(norm_bwd_apply_kernel<float>, dim3(ew_grid(nq)), dim3(NTHR), 0, st,
                            (const float*)dh, (const float*)h, (const float*)x, (const float*)g1, (float*)dx,
-                           nq, P, C, mean, rstd, s1, s2, act, slope);
+                           nq, P, C, mean, rstd, s1, s2, sgs, sscale, act, slope);
     MG_CHECK_LAUNCH("mg_norm_bwd_apply");
     return MG_OK;
 }

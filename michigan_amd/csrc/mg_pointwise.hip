@@ -177,7 +177,7 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, i
 }
 template <typename T>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx,
-                                   int N, int H, int W, int C, int Ho, int Wo)
+                                   int N, int H, int W, int C, int Ho, int Wo, int relu_in)
 {
     const int c4 = C / 4;
     const int64_t n = (int64_t)N * H * W * c4;
@@ -199,7 +199,7 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const T* __restrict
                 int arg = 0; float m = v[0][j];
 #pragma unroll
                 for (int k = 1; k < 4; ++k) if (v[k][j] > m) { m = v[k][j]; arg = k; }   // first maximum wins (ATen order)
-                o[j] = (arg == me) ? g[j] : 0.f;
+                o[j] = (arg == me && (!relu_in || m > 0.f)) ? g[j] : 0.f;     // relu_in: x is a ReLU's output -> its backward mask rides along
             }
         }
         ET<T>::store4(dx + i * 4, o);
@@ -444,15 +444,84 @@ extern "C" int mg_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t N,
     MG_CHECK_LAUNCH("mg_maxpool2_fwd");
     return MG_OK;
 }
-extern "C" int mg_maxpool2_bwd(const void* dy, const void* x, void* dx, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, void* stream)
+// out[p][0..8) = [planar[n][0..cp)[p] | nhwc[p][0..cf) | 0 ...]: the patch discriminators' input pixel (7 channels: tag one-hot,
+// orientation, image; pix2pix_model.py:559-566) assembled in the kernels' NHWC layout with its zero pad channel in ONE pass from
+// the reference's planar fp32 maps and the generator's NHWC image (eager: two concatenations, a permute + cast + copy, a pad).
+template <typename T>
+__global__ void assemble_nhwc8_kernel(const float* __restrict__ planar, int cp, const T* __restrict__ nhwc, int cs, int cf,
+                                      T* __restrict__ out, int64_t npix, int64_t hw)
+{
+    GRID_STRIDE(i, npix) {
+        const int64_t n = i / hw, p = i - n * hw;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float t = 0.f;
+            if (c < cp) t = planar[((size_t)n * cp + c) * hw + p];
+            else if (c - cp < cf) t = ET<T>::load1(nhwc + (size_t)i * cs + (c - cp));
+            v[c] = t;
+        }
+        f32x4_t a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        ET<T>::store4(out + (size_t)i * 8, a);
+        ET<T>::store4(out + (size_t)i * 8 + 4, b);
+    }
+}
+
+extern "C" int mg_assemble_nhwc8(const float* planar, int32_t cp, const void* nhwc, int32_t cs, int32_t cf, void* out, int32_t dtype,
+                                 int32_t N, int64_t HW, void* stream)
+{
+    MG_CHECK_ARG(out && (planar || cp == 0) && (nhwc || cf == 0), "mg_assemble_nhwc8: null pointer");
+    MG_CHECK_ARG((dtype == MG_F32 || dtype == MG_BF16) && N > 0 && HW > 0 && cp >= 0 && cf >= 0 && cp + cf <= 8 && cf <= cs,
+                 "mg_assemble_nhwc8: bad geometry (cp + cf <= 8, cf <= cs)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t npix = (int64_t)N * HW;
+    if (dtype == MG_BF16) hipLaunchKernelGGL(assemble_nhwc8_kernel<uint16_t>, dim3(ew_grid(npix)), dim3(NTHR), 0, st, planar, cp, (const uint16_t*)nhwc, cs, cf, (uint16_t*)out, npix, HW);
+    else hipLaunchKernelGGL(assemble_nhwc8_kernel<float>, dim3(ew_grid(npix)), dim3(NTHR), 0, st, planar, cp, (const float*)nhwc, cs, cf, (float*)out, npix, HW);
+    MG_CHECK_LAUNCH("mg_assemble_nhwc8");
+    return MG_OK;
+}
+
+// out = (g1 + g2) * act'(y): the gradient of an activation's output that has TWO consumers (a ReLU tap of the VGG tower feeding
+// the next conv and the perceptual loss; a background-encoder feature feeding the next layer and the blend), summed and pushed
+// through the activation in one pass instead of autograd's add (2r + 1w) followed by act_bwd (2r + 1w).  g2 may be NULL.
+template <typename T>
+__global__ void grad_sum_act_kernel(const T* __restrict__ g1, const T* __restrict__ g2, const T* __restrict__ y, T* __restrict__ out,
+                                    int64_t nquads, int act, float slope)
+{
+    GRID_STRIDE(i, nquads) {
+        f32x4_t a = ET<T>::load4(g1 + i * 4);
+        if (g2) { const f32x4_t b = ET<T>::load4(g2 + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += b[j]; }
+        const f32x4_t v = ET<T>::load4(y + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] *= mg_act_grad_from_out(v[j], act, slope);
+        ET<T>::store4(out + i * 4, a);
+    }
+}
+
+extern "C" int mg_grad_sum_act(const void* g1, const void* g2, const void* y, void* out, int32_t dtype, int64_t numel, int32_t act,
+                               float slope, void* stream)
+{
+    MG_CHECK_ARG(g1 && y && out, "mg_grad_sum_act: null pointer");
+    MG_CHECK_ARG((dtype == MG_F32 || dtype == MG_BF16) && numel > 0 && (numel % 4) == 0, "mg_grad_sum_act: numel must be a positive multiple of 4");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t nq = numel / 4;
+    if (dtype == MG_BF16) hipLaunchKernelGGL(grad_sum_act_kernel<uint16_t>, dim3(ew_grid(nq)), dim3(NTHR), 0, st, (const uint16_t*)g1, (const uint16_t*)g2, (const uint16_t*)y, (uint16_t*)out, nq, act, slope);
+    else hipLaunchKernelGGL(grad_sum_act_kernel<float>, dim3(ew_grid(nq)), dim3(NTHR), 0, st, (const float*)g1, (const float*)g2, (const float*)y, (float*)out, nq, act, slope);
+    MG_CHECK_LAUNCH("mg_grad_sum_act");
+    return MG_OK;
+}
+
+extern "C" int mg_maxpool2_bwd(const void* dy, const void* x, void* dx, int32_t dtype, int32_t N, int32_t H, int32_t W, int32_t C, int32_t relu_input, void* stream)
 {
     MG_EW_GEOM("mg_maxpool2_bwd"); MG_CHECK_ARG(dy && x && dx, "mg_maxpool2_bwd: null pointer");
     MG_CHECK_ARG(H >= 2 && W >= 2, "mg_maxpool2_bwd: H, W must be >= 2");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int Ho = H / 2, Wo = W / 2;
     const int g = ew_grid((int64_t)N * H * W * (C / 4));
-    if (dtype == MG_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<uint16_t>, dim3(g), dim3(NTHR), 0, st, (const uint16_t*)dy, (const uint16_t*)x, (uint16_t*)dx, N, H, W, C, Ho, Wo);
-    else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(NTHR), 0, st, (const float*)dy, (const float*)x, (float*)dx, N, H, W, C, Ho, Wo);
+    if (dtype == MG_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<uint16_t>, dim3(g), dim3(NTHR), 0, st, (const uint16_t*)dy, (const uint16_t*)x, (uint16_t*)dx, N, H, W, C, Ho, Wo, relu_input);
+    else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(NTHR), 0, st, (const float*)dy, (const float*)x, (float*)dx, N, H, W, C, Ho, Wo, relu_input);
     MG_CHECK_LAUNCH("mg_maxpool2_bwd");
     return MG_OK;
 }

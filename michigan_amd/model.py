@@ -156,11 +156,12 @@ class Pix2PixModel(nn.Module):
         (+1 zero channel so that a pixel is 16 bytes) instead of an NCHW concat followed by a transpose."""
         from . import ops
         dt = fake_image.dtype
-        cond = ops.to_nhwc(torch.cat([d["input_tag"], self.orientation_planes(d)], dim=1), dt)      # [N,H,W,4]
-        zero = cond.new_zeros(cond.shape[:3] + (1,))
-        fake = torch.cat([cond, fake_image.permute(0, 2, 3, 1), zero], dim=3)
-        real = torch.cat([cond, ops.to_nhwc(d["image_tag"], dt), zero], dim=3)
-        out = self.netD(torch.cat([fake, real], dim=0).permute(0, 3, 1, 2))
+        n, _, h, w = fake_image.shape
+        cond = torch.cat([d["input_tag"], self.orientation_planes(d)], dim=1)                 # [N,4,H,W] fp32
+        both = torch.empty((2 * n, h, w, 8), dtype=dt, device=fake_image.device)
+        ops.assemble_nhwc8(both, n, torch.cat([cond, d["image_tag"]], dim=1))                  # real half: all planar, no gradient
+        both = ops.assemble_nhwc8(both, 0, cond, fake_image.permute(0, 2, 3, 1), cf=3)         # fake half: the generator's NHWC image
+        out = self.netD(both.permute(0, 3, 1, 2))
         half = lambda t: t.size(0) // 2
         pred_fake = [[t[:half(t)] for t in p] for p in out]
         pred_real = [[t[half(t):] for t in p] for p in out]

@@ -113,5 +113,9 @@ class VGG19(nn.Module):
                     x = layer(x, act=ops.ACT_RELU)
                 elif isinstance(layer, _Pool):
                     x = layer(x)
-            outs.append(ops.to_nchw(x))
+            if si < 4:
+                x, tap = ops.act_tap(x)          # relu{1..4}_1 feed the next conv AND the perceptual loss: one fused gradient pass
+            else:
+                tap = x
+            outs.append(ops.to_nchw(tap))
         return outs

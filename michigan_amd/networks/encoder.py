@@ -138,10 +138,11 @@ class BackgroundEncode2(BaseNetwork):
             grown = F.max_pool2d(F.max_pool2d(hair, (k, 1), 1, (int(k / 2), 0)), (1, k), 1, (0, int(k / 2)))
             back = 1 - grown
         inp = noise if self.opt.random_noise_background else image * back + noise * (1 - back)
-        x0 = self.conv1(ops.pad_channels(ops.to_nhwc(inp, self.compute_dtype), 8))
-        x1 = self.layer1(x0)
-        x2 = self.layer2(x1)
-        x3 = self.layer3(x2)
+        # every feature map feeds the next layer AND the generator's blend (ConvBlock ends in a ReLU): two-consumer taps
+        x0, f0 = ops.act_tap(self.conv1(ops.pad_channels(ops.to_nhwc(inp, self.compute_dtype), 8)))
+        x1, f1 = ops.act_tap(self.layer1(x0))
+        x2, f2 = ops.act_tap(self.layer2(x1))
+        x3 = f3 = self.layer3(x2)
         sh, sw = back.shape[2], back.shape[3]
         masks = [F.interpolate(back, size=(int(sh / d), int(sw / d)), mode="nearest") for d in (8, 4, 2)] + [back]
-        return [x3, x2, x1, x0], masks
+        return [f3, f2, f1, f0], masks

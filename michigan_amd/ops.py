@@ -715,10 +715,9 @@ class _SpadeFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if work is not None:
                 work.wait()
-            s = (sums[0] / count).float().contiguous()
             dx = torch.empty_like(x)
             be.mg_norm_bwd_apply(_p(dh), hp, _p(x), _p(g1), _dt(x), 1, p, c, _p(mean), _p(rstd),
-                                 _p(s[0]), _p(s[1]), act, slope, _p(dx), _stream(x))
+                                 _p(sums[0, 0]), _p(sums[0, 1]), 2 * c, 1.0 / float(count), act, slope, _p(dx), _stream(x))
         if db is not None:
             db = db.reshape(rows // 64, 2, 32)
             dbg, dbb = db[:, 0].reshape(-1)[:c], db[:, 1].reshape(-1)[:c]
@@ -887,11 +886,9 @@ class _InstanceNormActFn(torch.autograd.Function):
         ws = torch.empty(max(int(be.mg_stats_workspace(n, p, c)), 4), dtype=torch.uint8, device=x.device)
         be.mg_norm_bwd_reduce(_p(dy), _p(y), _p(x), None, _dt(x), n, p, c, _p(mean), _p(rstd), act, slope,
                               None, _p(sums), _p(ws), _stream(x))
-        s1 = (sums[:, 0] / p).contiguous()
-        s2 = (sums[:, 1] / p).contiguous()
         dx = torch.empty_like(x)
-        be.mg_norm_bwd_apply(_p(dy), _p(y), _p(x), None, _dt(x), n, p, c, _p(mean), _p(rstd), _p(s1), _p(s2),
-                             act, slope, _p(dx), _stream(x))
+        be.mg_norm_bwd_apply(_p(dy), _p(y), _p(x), None, _dt(x), n, p, c, _p(mean), _p(rstd), _p(sums[0, 0]), _p(sums[0, 1]),
+                             2 * c, 1.0 / float(p), act, slope, _p(dx), _stream(x))
         return dx, None, None, None
 
 
@@ -950,7 +947,8 @@ class _AvgPoolFn(torch.autograd.Function):
 
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, x_relu=False):
+        ctx.x_relu = bool(x_relu)
         x = _nhwc(x)
         n, h, w, c = _geom(x)
         y = torch.empty((n, h // 2, w // 2, c), dtype=x.dtype, device=x.device)
@@ -964,8 +962,11 @@ class _MaxPoolFn(torch.autograd.Function):
         dy = dy.contiguous()
         n, h, w, c = x.shape
         dx = torch.empty_like(x)
-        C.backend().mg_maxpool2_bwd(_p(dy), _p(x), _p(dx), _dt(x), n, h, w, c, _stream(x))
-        return dx
+        fuse = ctx.x_relu and FUSE_RELU_MASK
+        C.backend().mg_maxpool2_bwd(_p(dy), _p(x), _p(dx), _dt(x), n, h, w, c, 1 if fuse else 0, _stream(x))
+        if fuse:                      # dx already carries the mask of the ReLU that produced x: its conv skips act_backward (see conv_dgrad)
+            _RELU_MASKED[dx.data_ptr()] = (x.data_ptr(), dx._version)
+        return dx, None
 
 
 class _BlendFn(torch.autograd.Function):
@@ -1042,7 +1043,89 @@ def avgpool3s2(x):
 
 def maxpool2(x):
     """nn.MaxPool2d(2, 2) on NHWC."""
-    return _MaxPoolFn.apply(x)
+    return _MaxPoolFn.apply(x, getattr(x, "_mg_relu_out", False))
+
+
+class _AssembleFn(torch.autograd.Function):
+    """dst[n0:n0+N] = [planar | image[..., :cf] | 0] per pixel (mg_assemble_nhwc8); gradient to the NHWC image only."""
+
+    @staticmethod
+    def forward(ctx, image, planar, dst, n0, cf):
+        n, h, w, cs = image.shape
+        cp = planar.shape[1]
+        C.backend().mg_assemble_nhwc8(_p(planar), cp, _p(image), cs, cf, _p(dst[n0:n0 + n]), _dt(dst), n, h * w, _stream(dst))
+        ctx.meta = (n0, n, cp, cf, cs)
+        ctx.mark_dirty(dst)
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        n0, n, cp, cf, cs = ctx.meta
+        dimg = g[n0:n0 + n, :, :, cp:cp + cf]
+        if cs != cf:
+            dimg = F.pad(dimg, (0, cs - cf))
+        return dimg.contiguous(), None, None, None, None
+
+
+def assemble_nhwc8(dst: torch.Tensor, n0: int, planar: torch.Tensor, image: Optional[torch.Tensor] = None, cf: int = 0) -> torch.Tensor:
+    """Fill dst[n0 : n0 + N] ([*, H, W, 8] NHWC, compute dtype) with [planar fp32 NCHW maps | first cf channels of the NHWC
+    `image` | zeros] per pixel, one launch; differentiable w.r.t. `image`."""
+    planar = planar.detach().float().contiguous()
+    if image is None:
+        n, _, h, w = planar.shape
+        C.backend().mg_assemble_nhwc8(_p(planar), planar.shape[1], None, 0, 0, _p(dst[n0:n0 + n]), _dt(dst), n, h * w, _stream(dst))
+        return dst
+    image = _nhwc(image)
+    if image.dtype != dst.dtype:
+        image = image.to(dst.dtype)
+    if image.requires_grad and torch.is_grad_enabled():
+        return _AssembleFn.apply(image, planar, dst, n0, cf)
+    n, h, w, cs = image.shape
+    C.backend().mg_assemble_nhwc8(_p(planar), planar.shape[1], _p(image), cs, cf, _p(dst[n0:n0 + n]), _dt(dst), n, h * w, _stream(dst))
+    return dst
+
+
+class _ActTapFn(torch.autograd.Function):
+    """Identity on an activation's output `a` that has two consumers; returns two aliases.  Its backward adds the two incoming
+    gradients AND applies the activation's derivative in one pass (mg_grad_sum_act), then tells the producing conv that its
+    activation backward is done (the _RELU_MASKED record) -- instead of autograd's add followed by act_backward."""
+
+    @staticmethod
+    def forward(ctx, a, act, slope):
+        ctx.save_for_backward(a)
+        ctx.cfg = (act, slope)
+        return a.view_as(a), a.view_as(a)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        (a,) = ctx.saved_tensors
+        act, slope = ctx.cfg
+        if g1 is None and g2 is None:
+            return None, None, None
+        if g1 is None:
+            g1, g2 = g2, None
+        g1 = g1.contiguous()
+        # a gradient that a consumer's data-gradient epilogue / max-pool backward already masked with this ReLU stays correct
+        # under a second multiplication by the same 0/1 mask; drop its record, the sum gets a new one
+        _RELU_MASKED.pop(g1.data_ptr(), None)
+        if g2 is not None:
+            g2 = g2.contiguous()
+            _RELU_MASKED.pop(g2.data_ptr(), None)
+        out = torch.empty_like(a)
+        C.backend().mg_grad_sum_act(_p(g1), _p(g2), _p(a), _p(out), _dt(a), a.numel(), act, slope, _stream(a))
+        if act == ACT_RELU:
+            _RELU_MASKED[out.data_ptr()] = (a.data_ptr(), out._version)
+        return out, None, None
+
+
+def act_tap(a: torch.Tensor, act: int = ACT_RELU, slope: float = 0.2):
+    """(a1, a2): two aliases of the activation output `a` for its two consumers (see _ActTapFn).  ReLU only: for other
+    activations the producer still runs its own activation backward, so the tap must not apply the derivative."""
+    if act != ACT_RELU or not (torch.is_grad_enabled() and a.requires_grad) or a.numel() % 4 or not FUSE_RELU_MASK:
+        return a, a
+    a1, a2 = _ActTapFn.apply(a, act, slope)
+    a1._mg_relu_out = a2._mg_relu_out = getattr(a, "_mg_relu_out", False)
+    return a1, a2
 
 
 def blend(bg, x, hair_mask, back_mask, *, act: int = ACT_NONE, slope: float = 0.2):

@@ -242,10 +242,10 @@ class EmulatorBackend:
             _view(d.dx, (P, C), td)[:] = total.to(td)
         return 0
 
-    def mg_norm_bwd_apply(self, dh, h, x, g1, dtype, G, P, C, mean, rstd, s1, s2, act, slope, dx, stream=None):
+    def mg_norm_bwd_apply(self, dh, h, x, g1, dtype, G, P, C, mean, rstd, s1, s2, sum_gstride, sum_scale, act, slope, dx, stream=None):
         _, xh, dxh, rs = self._bwd_common(dh, h, x, g1, dtype, G, P, C, mean, rstd, act, slope)
-        a = _view(s1, (G, 1, C), torch.float32).double()
-        b = _view(s2, (G, 1, C), torch.float32).double()
+        a = torch.stack([_view(_addr(s1) + 4 * g * sum_gstride, (C,), torch.float32) for g in range(G)]).double().view(G, 1, C) * sum_scale
+        b = torch.stack([_view(_addr(s2) + 4 * g * sum_gstride, (C,), torch.float32) for g in range(G)]).double().view(G, 1, C) * sum_scale
         td = _TD[dtype]
         _view(dx, (G, P, C), td)[:] = (rs * (dxh - a - xh * b)).to(td)
         return 0
@@ -326,7 +326,25 @@ class EmulatorBackend:
         _view(y, (N, Ho, Wo, C), td)[:] = xv.amax((2, 4))
         return 0
 
-    def mg_maxpool2_bwd(self, dy, x, dx, dtype, N, H, W, C, stream=None):
+    def mg_assemble_nhwc8(self, planar, cp, nhwc, cs, cf, out, dtype, N, HW, stream=None):
+        td = _TD[dtype]
+        o = _view(out, (N, HW, 8), td)
+        o.zero_()
+        if cp:
+            o[:, :, :cp] = _view(planar, (N, cp, HW), torch.float32).permute(0, 2, 1).to(td)
+        if cf:
+            o[:, :, cp:cp + cf] = _view(nhwc, (N, HW, cs), td)[:, :, :cf]
+        return 0
+
+    def mg_grad_sum_act(self, g1, g2, y, out, dtype, numel, act, slope, stream=None):
+        td = _TD[dtype]
+        g = _view(g1, (numel,), td).double()
+        if _addr(g2):
+            g = g + _view(g2, (numel,), td).double()
+        _view(out, (numel,), td)[:] = (g * _act_grad_from_out(_view(y, (numel,), td).double(), act, slope)).to(td)
+        return 0
+
+    def mg_maxpool2_bwd(self, dy, x, dx, dtype, N, H, W, C, relu_input=0, stream=None):
         td = _TD[dtype]
         Ho, Wo = H // 2, W // 2
         xv = _view(x, (N, H, W, C), td).float()[:, :2 * Ho, :2 * Wo].reshape(N, Ho, 2, Wo, 2, C)
@@ -343,6 +361,8 @@ class EmulatorBackend:
         g.scatter_(4, arg[..., None], d[..., None])
         full = torch.zeros((N, H, W, C))
         full[:, :2 * Ho, :2 * Wo] = g.reshape(N, Ho, Wo, C, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(N, 2 * Ho, 2 * Wo, C)
+        if relu_input:
+            full = full * (_view(x, (N, H, W, C), td).float() > 0)
         _view(dx, (N, H, W, C), td)[:] = full.to(td)
         return 0
 

@@ -834,3 +834,36 @@ def test_spade_pair_with_folded_upsample(dt, up):
         _close(f"pair {dt} up={up} {nm}: hip vs emulator", hip_f[i], emu_f[i], tol)
         _close(f"pair {dt} up={up} {nm}: fused vs unfused (emulator)", emu_f[i], emu_u[i], 1e-6 if dt == "f32" else 2.0 ** -6)
         _close(f"pair {dt} up={up} {nm}: fused vs unfused (hip)", hip_f[i], hip_u[i], tol * (4 if nm == "dx" and dt == "bf16" else 1))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_relu_tap_and_masked_maxpool_backward(dt):
+    """A ReLU output with two consumers (act_tap -> mg_grad_sum_act) and a max-pool whose backward carries the producing ReLU's
+    mask (mg_maxpool2_bwd relu_input): conv+ReLU -> {2x2 max-pool -> conv, loss tap} on the HIP kernels vs the contract
+    emulator and, in fp32, vs torch autograd of the same graph."""
+    import torch.nn.functional as F
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(51)
+    x = torch.randn(2, 12, 20, 16, generator=g).to(DT[dt]).requires_grad_()
+    w1 = torch.randn(32, 16, 3, 3, generator=g).mul_(0.1).requires_grad_()
+    w2 = torch.randn(24, 32, 3, 3, generator=g).mul_(0.1).requires_grad_()
+    gt = torch.randn(2, 12, 20, 32, generator=g).to(DT[dt])
+    gp = torch.randn(2, 6, 10, 24, generator=g).to(DT[dt])
+
+    def fn(x, w1, w2, gt, gp):
+        y = ops.conv2d(x, w1, None, padding=1, act=ops.ACT_RELU)
+        y1, y2 = ops.act_tap(y)
+        z = ops.conv2d(ops.maxpool2(y1), w2, None, padding=1)
+        loss = (z.float() * gp.float()).sum() + (y2.float() * gt.float()).sum()
+        return [y, z] + list(torch.autograd.grad(loss, [x, w1, w2]))
+    (hip, _), (ref, _) = _both(fn, (x, w1, w2, gt, gp))
+    for i, nm in enumerate(["y", "z", "dx", "dw1", "dw2"]):
+        _close(f"relu tap {dt} {nm}", hip[i], ref[i], 5e-5 if dt == "f32" else 2.0 ** -6)
+    if dt == "f32":
+        xt = x.detach().permute(0, 3, 1, 2).requires_grad_()
+        y = F.relu(F.conv2d(xt, w1, padding=1))
+        z = F.conv2d(F.max_pool2d(y, 2), w2, padding=1)
+        loss = (z * gp.permute(0, 3, 1, 2)).sum() + (y * gt.permute(0, 3, 1, 2)).sum()
+        want = torch.autograd.grad(loss, [xt, w1, w2])
+        _close("relu tap f32 dx vs torch", hip[2], want[0].permute(0, 2, 3, 1), 1e-4)
+        _close("relu tap f32 dw1 vs torch", hip[3], want[1], 1e-4)

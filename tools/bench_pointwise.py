@@ -38,7 +38,7 @@ row("channel stats (BN sum, sum^2)  [8,512,512,128] bf16", T, timeit(lambda: be.
 dgb = torch.empty(n, h, w, 2 * c, device="cuda", dtype=bf)
 row("SPADE bwd reduce (4 reads, d[gamma|beta] write)", 6 * T, timeit(lambda: be.mg_norm_bwd_reduce(P(dh), P(hh), P(x), P(g1), 1, 1, p, c, P(mean), P(rstd), 2, 0.2, P(dgb), P(sums), P(ws), st)))
 dx = torch.empty_like(x); s1 = torch.zeros(c, device="cuda"); s2 = torch.zeros(c, device="cuda")
-row("SPADE bwd apply (4 reads, dx write)", 5 * T, timeit(lambda: be.mg_norm_bwd_apply(P(dh), P(hh), P(x), P(g1), 1, 1, p, c, P(mean), P(rstd), P(s1), P(s2), 2, 0.2, P(dx), st)))
+row("SPADE bwd apply (4 reads, dx write)", 5 * T, timeit(lambda: be.mg_norm_bwd_apply(P(dh), P(hh), P(x), P(g1), 1, 1, p, c, P(mean), P(rstd), P(s1), P(s2), c, 1.0, 2, 0.2, P(dx), st)))
 row("activation backward (2 reads, 1 write)", 3 * T, timeit(lambda: ops.act_backward(dh, hh, ops.ACT_LRELU, 0.2)))
 xs = torch.randn(n, 256, 256, c, device="cuda").to(bf)
 row("nearest 2x upsample 256^2 -> 512^2 x128", xs.numel() * 2 + T, timeit(lambda: ops.upsample2x(xs)))
