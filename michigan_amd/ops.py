@@ -631,6 +631,26 @@ def _count_collective(kind: str):
     parallel.COLLECTIVES[kind] += 1
 
 
+_BIAS_PAIR_CACHE = {}
+
+
+def spade_bias_rows(bg: torch.Tensor, bb: torch.Tensor) -> torch.Tensor:
+    """_interleave32 of the (mlp_gamma.bias, mlp_beta.bias) parameters, cached until either changes (tensor versions + the
+    optimiser arena's update count, like pack_weight): 18 SPADE layers x 2 generator forwards re-built it every time."""
+    if not (isinstance(bg, torch.nn.Parameter) and isinstance(bb, torch.nn.Parameter)):
+        return _interleave32(bg.detach().float(), bb.detach().float()).contiguous()
+    key = (bg.data_ptr(), bb.data_ptr())
+    state = (bg._version, bb._version, _arena_epoch(bg), _arena_epoch(bb))
+    hit = _BIAS_PAIR_CACHE.get(key)
+    if hit is not None and hit[0] == state and hit[1]() is bg and hit[2]() is bb:
+        return hit[3]
+    rows = _interleave32(bg.detach().float(), bb.detach().float()).contiguous()
+    if len(_BIAS_PAIR_CACHE) > 1024:
+        _BIAS_PAIR_CACHE.clear()
+    _BIAS_PAIR_CACHE[key] = (state, weakref.ref(bg), weakref.ref(bb), rows)
+    return rows
+
+
 def _interleave32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """[C], [C] -> [2*roundup(C,32)] in the fused-SPADE GEMM row order ([32 gamma | 32 beta] blocks)."""
     c = a.numel()
@@ -654,7 +674,7 @@ class _SpadeFn(torch.autograd.Function):
         kh = w_gamma.shape[2]
         rows = 2 * _roundup(c, 32)
         wp = pack_weight(w_gamma, w_beta, x.dtype, _roundup(rows, 128), actv.shape[3], 0)
-        bias = _interleave32(b_gamma.detach().float(), b_beta.detach().float()).contiguous()
+        bias = spade_bias_rows(b_gamma, b_beta)
         out = torch.empty_like(x)
         # (1 + gamma) is only needed by the backward pass: the no_grad generator forward of the
         # discriminator step (pix2pix_model.py:376) does not write it
@@ -746,7 +766,7 @@ class _SpadePairFn(torch.autograd.Function):
                 raise ValueError("spade_modulate_pair: mlp_gamma / mlp_beta weights have the wrong shape")
             kh = wg.shape[2]
             wp = pack_weight(wg, wb, x.dtype, _roundup(rows, 128), actv.shape[3], 0)
-            bias = _interleave32(bg.detach().float(), bb.detach().float()).contiguous()
+            bias = spade_bias_rows(bg, bb)
             out = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
             g1 = torch.empty_like(out) if need else None
             _launch_conv(actv, wp, out, bias, fwd_taps(kh, kh, kh // 2), Hj=h, Wj=w, isy=1, isx=1, cout=c, cout_gemm=rows,
