@@ -73,7 +73,12 @@ class ConvMeter:
             # conv-granular algorithmic bytes of a SPADE launch: activation map in, x in, h (+ 1+gamma when training) out, weights
             g1 = kw.get("gamma_out")
             abytes = (inp.numel() + 2 * out.numel() + (out.numel() if g1 is not None else 0) + wt.numel()) * inp.element_size() if dominant else 0
-            recs.append((s, e, flops, inp.dtype, dominant, abytes))
+            # conv-granular algorithmic bytes of ANY launch (input map, output tile of this launch, residual / x / 1+gamma streams,
+            # weights) -> its arithmetic intensity decides which roof it sits under
+            opix = n * kw["Hj"] * kw["Wj"] * kw["cout"]
+            streams = 1 + (kw.get("resid") is not None) + (kw.get("spade_x") is not None) + (g1 is not None) + (kw.get("relu_mask") is not None)
+            gbytes = (inp.numel() + opix * streams + wt.numel()) * inp.element_size()
+            recs.append((s, e, flops, inp.dtype, dominant, abytes, gbytes))
         self.ops._launch_conv = timed
         return self
 
@@ -85,6 +90,15 @@ class ConvMeter:
         ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
         fl = sum(r[2] for r in self.records)
         dom = [r for r in self.records if r[4]]
+        ridge = PEAK_BF16_TFLOPS * 1e12 / 8e12 if self.records and self.records[0][3] == torch.bfloat16 else PEAK_F32_TFLOPS * 1e12 / 8e12
+        mf = [r for r in self.records if r[2] / r[6] >= ridge]            # above the ridge (flop/byte at 8 TB/s): MFMA roof
+        hb = [r for r in self.records if r[2] / r[6] < ridge]             # below it: HBM roof
+        split = {"ridge_flop_per_byte": round(ridge, 1),
+                 "mfma_bound": {"launches": len(mf), "ms": round(sum(r[0].elapsed_time(r[1]) for r in mf), 3),
+                                "tflops": round(sum(r[2] for r in mf) / max(sum(r[0].elapsed_time(r[1]) for r in mf), 1e-9) / 1e9, 1)},
+                 "hbm_bound": {"launches": len(hb), "ms": round(sum(r[0].elapsed_time(r[1]) for r in hb), 3),
+                               "algorithmic_gb_per_s": round(sum(r[6] for r in hb) / max(sum(r[0].elapsed_time(r[1]) for r in hb), 1e-9) / 1e6, 1)}}
+        self.split = split
         return len(self.records), ms, fl, (len(dom), sum(r[0].elapsed_time(r[1]) for r in dom), sum(r[2] for r in dom), sum(r[5] for r in dom))
 
 
@@ -188,7 +202,9 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             all_conv = {"kernels": "every mg_conv_taps launch of one step (forward + data gradients)", "launches": n,
                         "achieved": round(ach, 1), "frac": round(ach / peak, 4), "kernel_ms_per_step": round(ms, 3),
-                        "algorithmic_gflop_per_step": round(fl / 1e9, 1)}
+                        "algorithmic_gflop_per_step": round(fl / 1e9, 1), "by_roof": m.split}
+            m.split["mfma_bound"]["frac"] = round(m.split["mfma_bound"]["tflops"] / peak, 4)
+            m.split["hbm_bound"]["frac"] = round(m.split["hbm_bound"]["algorithmic_gb_per_s"] / 8000.0, 4)
             if dn:
                 # dominant kernel (most time per step in the rocprofv3 kernel stats): the fused SPADE gamma|beta conv + modulation
                 dach = dfl / (dms * 1e-3) / 1e12
