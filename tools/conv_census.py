@@ -54,17 +54,25 @@ for (kind, k), ds in groups.items():
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 5
     kd = dict(k)
+    gb = 0.0
     if kind == "conv":
         gf = 2.0 * kd["N"] * kd["Hj"] * kd["Wj"] * kd["Cout_gemm"] * kd["Cin"] * kd["ntaps"] / 1e9
+        streams = 1 + int(kd["resid"]) + int(kd["x"]) + int(kd["gamma_out"])
+        gb = (kd["N"] * kd["Hin"] * kd["Win"] * kd["Cin"] + kd["N"] * kd["Hj"] * kd["Wj"] * kd["Cout"] * streams + kd["ntaps"] * kd["CoutP"] * kd["Cin"]) * 2 / 1e9
         desc = f"N{kd['N']} in{kd['Hin']}x{kd['Win']}x{kd['Cin']} -> {kd['Hj']}x{kd['Wj']}x{kd['Cout_gemm']} t{kd['ntaps']} s{kd['isy']} os{kd['osy']} epi{kd['epilogue']} act{kd['act']}"
     else:
         gf = 2.0 * kd["N"] * kd["Hj"] * kd["Wj"] * kd["Cg"] * kd["Cin"] * kd["ntaps"] / 1e9
         desc = f"N{kd['N']} x{kd['Hin']}x{kd['Win']}x{kd['Cin']} dy{kd['Hj']}x{kd['Wj']}x{kd['Cg']} t{kd['ntaps']} s{kd['isy']} bias{int(kd['dbias'])}"
-    res.append((ms * len(ds), kind, len(ds), ms, gf / ms, desc))
+    res.append((ms * len(ds), kind, len(ds), ms, gf / ms, desc, gb, gf))
 res.sort(reverse=True)
 for kind in ("conv", "wgrad"):
     tot = sum(r[0] for r in res if r[1] == kind)
     print(f"== {kind}: {tot:.2f} ms/step over {sum(r[2] for r in res if r[1] == kind)} launches")
-    for t, k, n, ms, tf, desc in res:
+    for t, k, n, ms, tf, desc, gb, gf in res:
         if k == kind and t > 0.15:
             print(f"  {t:7.2f} ms = {n:3d} x {ms:7.3f} ms  {tf:7.1f} TF/s  {desc}")
+# launches below the bf16 ridge (312 flop per conv-granular byte): priced against HBM, everything listed
+hb = [r for r in res if r[1] == "conv" and r[6] > 0 and r[7] / r[6] < 312.5]
+print(f"== conv launches below the ridge: {sum(r[0] for r in hb):.2f} ms/step over {sum(r[2] for r in hb)} launches")
+for t, k, n, ms, tf, desc, gb, gf in hb:
+    print(f"  {t:7.3f} ms = {n:3d} x {ms:7.3f} ms  {gb / ms:7.2f} TB/s  AI {gf / gb:5.0f}  {desc}")
