@@ -9,7 +9,8 @@ from michigan_amd.model import Pix2PixTrainer, default_options
 from michigan_amd.synth import synth_batch
 
 be = _cabi.backend()
-SHAPES = [("spade 128->2x128 @512", 128, 128, 512, True), ("spade 128->2x256 @256", 128, 256, 256, True),
+SHAPES = [("conv 64->64 @512 (WM=1 geometry)", 64, 64, 512, False), ("conv 128->64 @512", 128, 64, 512, False),
+          ("spade 128->2x128 @512", 128, 128, 512, True), ("spade 128->2x256 @256", 128, 256, 256, True),
           ("conv 256->128 @512 (dgrad shape)", 256, 128, 512, False), ("conv 128->128 @512", 128, 128, 512, False),
           ("conv 512->256 @128", 512, 256, 128, False), ("conv 256->256 @128", 256, 256, 128, False)]
 g = torch.Generator().manual_seed(1)
