@@ -44,7 +44,9 @@ for name, cin, cout, hw, spade in SHAPES:
                 res.setdefault(ring, []).append(s.elapsed_time(e) / 10)
     be.mg_set_option(10, 0)
     print(f"{name:36s} ring3 {min(res[3])*1e3:7.1f} us {flops/min(res[3])/1e9:7.1f} TF/s | ring4 {min(res[4])*1e3:7.1f} us {flops/min(res[4])/1e9:7.1f} TF/s"
-          f" | no epilogue {min(res[13])*1e3:7.1f} us {flops/min(res[13])/1e9:7.1f} TF/s", flush=True)
+          f" | no epilogue {min(res[13])*1e3:7.1f} us {flops/min(res[13])/1e9:7.1f} TF/s"
+          f" | non-persistent {min(res[23])*1e3:7.1f} us (bitwise equal: {same})", flush=True)
+    be.mg_set_option(11, 1)
 
 opt = default_options(crop_size=512, gpu_ids=[0], compute_dtype="bf16")
 tr = Pix2PixTrainer(opt)
@@ -53,10 +55,11 @@ def step():
     tr.run_generator_one_step(data); tr.run_discriminator_one_step(data)
 for _ in range(3): step()
 be.mg_set_option(10, 0)
-for rep in range(2):
-    for ring in (3, 4):
-        be.mg_set_option(9, ring)
+be.mg_set_option(9, 3)
+for rep in range(3):
+    for ring in (0, 1):
+        be.mg_set_option(11, ring)
         step(); torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(6): step()
         torch.cuda.synchronize()
-        print(f"ring {ring}: {(time.perf_counter() - t0) / 6 * 1e3:.2f} ms/step", flush=True)
+        print(f"persistent small tiles {ring}: {(time.perf_counter() - t0) / 6 * 1e3:.2f} ms/step", flush=True)
