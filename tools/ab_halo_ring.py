@@ -31,10 +31,13 @@ for name, cin, cout, hw, spade in SHAPES:
         flops = 2.0 * n * hw * hw * cout * cin * 9
     res = {}
     with torch.no_grad():
+        be.mg_set_option(11, 0); ref_out = fn().clone()
+        be.mg_set_option(11, 1); same = torch.equal(fn(), ref_out)
         for rep in range(2):
-            for ring in (3, 4, 13):               # 13 = ring 3 without the epilogue (mg_set_option(10, 1)): main-loop time alone
+            for ring in (3, 4, 13, 23):           # 13 = without the epilogue (mg_set_option(10, 1)); 23 = one tile per workgroup also in the 64-channel geometry
                 be.mg_set_option(9, 4 if ring == 4 else 3)
                 be.mg_set_option(10, 1 if ring == 13 else 0)
+                be.mg_set_option(11, 0 if ring == 23 else 1)
                 for _ in range(3): fn()
                 torch.cuda.synchronize()
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
