@@ -23,7 +23,6 @@ int g_mg_conv_bigtiles = 1;      // allow the 128x256 / 256x256 tiles (mg_set_op
 extern int g_mg_wgrad3x3;          // mg_wgrad.hip (mg_set_option(3, v))
 extern int g_mg_conv_thin;         // mg_conv_thin.hip (mg_set_option(6, v))
 extern int g_mg_conv_dot;          // mg_conv_dot.hip (mg_set_option(8, v))
-int g_mg_conv_halo_persist = 1;   // persistent workgroups in the small-tile halo geometries (mg_set_option(11, v))
 int g_mg_conv_dbg_noepi = 0;     // MEASUREMENT ONLY (mg_set_option(10, 1)): the halo kernel returns before its epilogue -- wrong results, main-loop time
 int g_mg_conv_wide = 1;          // bf16 epilogues store 16 bytes per lane after a half-wave quad exchange (mg_set_option(7, v))
 int g_mg_conv_pipeline = 1;      // 0 = register-staged double buffer, 1 = LDS-DMA 3-stage ring (mg_set_option(0, v))
@@ -582,6 +581,5 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 8 && (value == 0 || value == 1)) { g_mg_conv_dot = value; return MG_OK; }
     if (key == 9 && (value == 3 || value == 4)) { g_mg_conv_halo_ring = value; return MG_OK; }
     if (key == 10 && (value == 0 || value == 1)) { g_mg_conv_dbg_noepi = value; return MG_OK; }
-    if (key == 11 && (value == 0 || value == 1)) { g_mg_conv_halo_persist = value; return MG_OK; }
     return mg_fail(MG_ERR_ARG, "mg_set_option: unknown key/value %d/%d", key, value);
 }

@@ -28,7 +28,6 @@ struct ConvK {              // kernel-side view of mg_conv_desc (passed by value
     int ksplit, ntiles;     // generic LDS-DMA kernel: split-K factor (1 = off) and tiles per K slice
     float* ws;              // split-K: fp32 partial sums [ksplit][ngemm][Cout_gemm]
     int wide;               // bf16 epilogue: lanes l and l+32 exchange quads so that every lane stores 16 contiguous bytes
-    int halo_tiles;         // halo kernel: total tiles of the launch (> gridDim.x: persistent workgroups walk them)
     int x_up;               // SPADE: x is the half-resolution source of a nearest 2x upsample (read at (y >> 1, x >> 1))
 };
 namespace {

@@ -32,7 +32,6 @@
 #endif
 
 extern int g_mg_conv_halo_big;     // mg_set_option(4, v): 0 = never use the 128 x 16x16 geometry
-extern int g_mg_conv_halo_persist; // mg_set_option(11, v): 0 = one tile per workgroup also in the small-tile geometries (A/B)
 extern int g_mg_conv_halo_ring;    // mg_set_option(9, v): weight-slab ring depth of the 128 x 16x16 geometry (3 or 4)
 
 namespace {
@@ -75,7 +74,7 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
 }
 
 template <typename T, int EPI, int WM, int NT, int RING = 3>
-__global__ __launch_bounds__(NTHR, ((NT == 4 || WM == 1) ? 2 : 3)) void conv3x3_halo_kernel(const ConvK d)
+__global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(const ConvK d)
 {
     using G = HaloGeom<WM, NT, RING>;
     constexpr int PF = RING - 1;                               // weight slabs in flight ahead of the tap being computed
@@ -94,21 +93,9 @@ __global__ __launch_bounds__(NTHR, ((NT == 4 || WM == 1) ? 2 : 3)) void conv3x3_
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hi = lane >> 5;
 
-    // Persistent workgroups for the 64-channel geometry (64 accumulator registers, room for the loop): a workgroup walks
-    // tiles vb, vb + gridDim.x, ... (gridDim.x is a multiple of 8, so it stays on its XCD and the tile <-> XCD map is that of the
-    // one-tile-per-workgroup launch).  On the 64-channel 512^2 layers (K = 576) launching, filling and draining a workgroup per 256
-    // pixels cost 41 % of the launch (246 us vs 145 us for the main loop alone, tools/ab_halo_ring.py).  Between tiles only a barrier:
-    // every wave is done with the LDS image (the epilogue's parameter reads included) before the next tile's DMA lands; the first
-    // counted vmcnt wait of the next tile also covers the epilogue's stores (they are older).  The other geometries keep one tile per
-    // workgroup: the loop pushed the big tile over 256 VGPRs (profiles/r02_halo_persistent_ab.txt) and the 8x16 tile over the 168 of its
-    // three waves per SIMD.
-    constexpr bool PERSIST = NT == 2 && WM == 1;      // the 64-channel geometry: LDS (61 KiB) already limits it to two workgroups per CU, so 256 VGPRs are there
-    int vb = blockIdx.x;
-    do {
-    if (PERSIST && vb != (int)blockIdx.x) __builtin_amdgcn_s_barrier();
     int tile;
     {
-        const int nblk = PERSIST ? d.halo_tiles : (int)gridDim.x, b = vb;
+        const int nblk = gridDim.x, b = blockIdx.x;
         const int q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
@@ -321,11 +308,9 @@ __global__ __launch_bounds__(NTHR, ((NT == 4 || WM == 1) ? 2 : 3)) void conv3x3_
     };
     if (d.wide & 2) {                            // measurement aid (mg_set_option(10, 1)): main loop only; one store keeps the MFMAs alive
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<T*>(d.out)[0] = (T)1;
-    } else {
-        conv_epilogue<T, MT, NT, EPI, TM_H>(d, acc, m0, pixmap, wm, wn, l31, hi, par);
+        return;
     }
-    vb += gridDim.x;
-    } while (PERSIST && vb < d.halo_tiles);
+    conv_epilogue<T, MT, NT, EPI, TM_H>(d, acc, m0, pixmap, wm, wn, l31, hi, par);
 }
 
 template <typename T, int EPI, int WM, int NT, int RING = 3>
@@ -335,13 +320,8 @@ int launch_halo_g(ConvK& k, hipStream_t st)
     k.tiles_m = (k.Cout_gemm + G::TM - 1) / G::TM;
     k.tiles_y = (k.Hin + G::TH - 1) / G::TH;
     k.tiles_x = (k.Win + TW - 1) / TW;
-    long nblk = (long)k.N * k.tiles_y * k.tiles_x * k.tiles_m;
+    const long nblk = (long)k.N * k.tiles_y * k.tiles_x * k.tiles_m;
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_taps(halo): bad grid %ld", nblk);
-    k.halo_tiles = (int)nblk;
-    if constexpr (NT == 2 && WM == 1) {
-        // persistent: as many workgroups as are resident at once (LDS-limited: 2 per CU at 61 KiB), a multiple of 8
-        if (g_mg_conv_halo_persist && nblk > 512) nblk = 512;
-    }
     static_assert(RING == 3 || 2 * G::LDS <= 160 * 1024, "LDS budget of the deep ring: two workgroups per CU");
     auto kern = conv3x3_halo_kernel<T, EPI, WM, NT, RING>;
     if constexpr (G::LDS > 65536) {

@@ -31,13 +31,10 @@ for name, cin, cout, hw, spade in SHAPES:
         flops = 2.0 * n * hw * hw * cout * cin * 9
     res = {}
     with torch.no_grad():
-        be.mg_set_option(11, 0); ref_out = fn().clone()
-        be.mg_set_option(11, 1); same = torch.equal(fn(), ref_out)
         for rep in range(2):
-            for ring in (3, 4, 13, 23):           # 13 = without the epilogue (mg_set_option(10, 1)); 23 = one tile per workgroup also in the 64-channel geometry
+            for ring in (3, 4, 13):               # 13 = ring 3 without the epilogue (mg_set_option(10, 1)): main-loop time alone
                 be.mg_set_option(9, 4 if ring == 4 else 3)
                 be.mg_set_option(10, 1 if ring == 13 else 0)
-                be.mg_set_option(11, 0 if ring == 23 else 1)
                 for _ in range(3): fn()
                 torch.cuda.synchronize()
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -47,9 +44,7 @@ for name, cin, cout, hw, spade in SHAPES:
                 res.setdefault(ring, []).append(s.elapsed_time(e) / 10)
     be.mg_set_option(10, 0)
     print(f"{name:36s} ring3 {min(res[3])*1e3:7.1f} us {flops/min(res[3])/1e9:7.1f} TF/s | ring4 {min(res[4])*1e3:7.1f} us {flops/min(res[4])/1e9:7.1f} TF/s"
-          f" | no epilogue {min(res[13])*1e3:7.1f} us {flops/min(res[13])/1e9:7.1f} TF/s"
-          f" | non-persistent {min(res[23])*1e3:7.1f} us (bitwise equal: {same})", flush=True)
-    be.mg_set_option(11, 1)
+          f" | no epilogue {min(res[13])*1e3:7.1f} us {flops/min(res[13])/1e9:7.1f} TF/s", flush=True)
 
 opt = default_options(crop_size=512, gpu_ids=[0], compute_dtype="bf16")
 tr = Pix2PixTrainer(opt)
@@ -58,11 +53,10 @@ def step():
     tr.run_generator_one_step(data); tr.run_discriminator_one_step(data)
 for _ in range(3): step()
 be.mg_set_option(10, 0)
-be.mg_set_option(9, 3)
-for rep in range(3):
-    for ring in (0, 1):
-        be.mg_set_option(11, ring)
+for rep in range(2):
+    for ring in (3, 4):
+        be.mg_set_option(9, ring)
         step(); torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(6): step()
         torch.cuda.synchronize()
-        print(f"persistent small tiles {ring}: {(time.perf_counter() - t0) / 6 * 1e3:.2f} ms/step", flush=True)
+        print(f"ring {ring}: {(time.perf_counter() - t0) / 6 * 1e3:.2f} ms/step", flush=True)
