@@ -118,11 +118,14 @@ __device__ __forceinline__ void conv_stage_params(const ConvK& d, int m0, float*
     }
 }
 
-// branch-free activation for the batched epilogue: NONE / RELU / LRELU as one select (TANH takes the generic path)
-__device__ __forceinline__ float mg_act_fast(float v, float neg, bool relu)
+// branch-free activation for the batched epilogue: NONE / RELU / LRELU are all  max(v, 0) + neg * min(v, 0)  with
+// neg = 1 / 0 / slope (TANH takes the generic path).  It has to be arithmetic: written as a select on a runtime `relu`
+// flag the compiler emitted two uniform branches PER ELEMENT (128 elements per lane in the big halo tile), and the
+// epilogue of a 128-channel 3x3 conv then took 55 % as long as its whole K loop (tools/probe_halo.py stamps,
+// profiles/r02_halo_probe.txt).
+__device__ __forceinline__ float mg_act_fast(float v, float neg, bool /*relu*/)
 {
-    float r = v > 0.f ? v : v * neg;
-    return relu ? fmaxf(v, 0.f) : r;
+    return fmaxf(v, 0.f) + neg * fminf(v, 0.f);
 }
 
 // Wide bf16 stores.  In the MFMA accumulator layout lane l (pixel l & 31, hi = l >> 5) holds channel quads
@@ -147,9 +150,28 @@ __device__ __forceinline__ uint4 mg_pair_swap(uint2 even, uint2 odd)
 // 4-channel group (the generic code below waits after every load; at 16-32 groups per lane that was longer than
 // the whole K loop of the 128-channel SPADE convs).  Addresses of non-existing pixels / channels are clamped
 // to a valid element and only the stores are predicated.  `wrow` = first GEMM row of the wave inside the tile.
-template <typename T, int MT, int NT, int EPI, int TM, typename PixMap>
+// Lean epilogue arithmetic.  An epilogue wave shares its SIMD with another workgroup's MFMA stream and gets roughly one VALU
+// issue per 10 cycles there (s_memrealtime stamps: a 16-value block of ~150 VALU took 0.78 us, profiles/r02_halo_probe.txt), so
+// the epilogue is priced in VALU instructions: the lean paths below use packed fp32 math (v_pk_add/mul/fma_f32 on register
+// pairs) and one specialised body per uniform case instead of per-element selects.  ACT: 0 none, 1 relu, 2 lrelu with slope in [0, 1].
+template <int ACT>
+__device__ __forceinline__ mg_f32x2_t mg_act2(mg_f32x2_t v, float neg)
+{
+    if constexpr (ACT == 0) return v;
+    else if constexpr (ACT == 1) { const mg_f32x2_t z = {0.f, 0.f}; return __builtin_elementwise_max(v, z); }
+    else return __builtin_elementwise_max(v, v * neg);           // v > 0 ? v : v * slope   for 0 <= slope <= 1
+}
+__device__ __forceinline__ mg_f32x2_t mg_pk(float a, float b) { const mg_f32x2_t v = {a, b}; return v; }
+__device__ __forceinline__ uint2 mg_pack_bf16x2x2(mg_f32x2_t a, mg_f32x2_t b) { uint2 u; u.x = f2bf2(a[0], a[1]); u.y = f2bf2(b[0], b[1]); return u; }
+
+struct EpiNoMark { __device__ __forceinline__ void operator()(int) const {} };      // measurement hook of the probe builds (mg_conv_halo.hip)
+
+// `xpre` (SPADE, bf16): the lane's 2*NT*2 x quads as raw 8-byte loads [half][nt][q], fetched by the caller BEFORE its main
+// loop (mg_conv_halo.hip) -- or nullptr: load them here.
+template <typename T, int MT, int NT, int EPI, int TM, typename PixMap, typename Mark = EpiNoMark>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&acc)[MT][NT], int m0, PixMap&& pixmap,
-                                                   int wm, int wn, int l31, int hi, const float* par)
+                                                   int wm, int wn, int l31, int hi, const float* par, Mark&& mark,
+                                                   const uint2 (&xpre)[2 * NT * 2], bool have_xpre)
 {
     T* __restrict__ Out = reinterpret_cast<T*>(d.out);
     const float neg = d.act == MG_ACT_NONE ? 1.f : (d.act == MG_ACT_RELU ? 0.f : d.slope);
@@ -160,16 +182,18 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         size_t upix = 0;
-        pok[nt] = pixmap(wn * NT * 32 + nt * 32 + l31, opix[nt], upix);
+        pok[nt] = pixmap(wn * NT * 32 + nt * 32 + l31, opix[nt], upix) && !(d.wide & 4);      // bit 2: measurement builds, stores off
         if constexpr (EPI == MG_EPI_SPADE) xoff[nt] = pok[nt] ? (unsigned)((d.x_up ? upix : opix[nt]) * d.Cout) : 0u;
         opix[nt] = pok[nt] ? opix[nt] * d.Cout : 0;
     }
 
+    mark(0);
     if constexpr (EPI == MG_EPI_PLAIN) {
         const T* __restrict__ Res = reinterpret_cast<const T*>(d.resid);
         const T* __restrict__ Msk = reinterpret_cast<const T*>(d.x);          // optional ReLU-output mask (dgrad)
         static_for<0, MT>([&](auto mt_) {
             constexpr int mt = decltype(mt_)::value;
+            mark(1 + mt * 5);
             const int lr = wm * MT * 32 + mt * 32 + hi * 4;       // + rq*8: this lane's GEMM rows inside the tile
             f32x4_t bias4[4];
 #pragma unroll
@@ -189,8 +213,51 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
                     }
             }
             const bool both = Res && Msk;
+            if constexpr (sizeof(T) == 2) {
+                // lean bodies (bf16, wide stores): {no aux} x {none, relu, lrelu}, {residual, mask} x {none}; anything else below
+                const int ak = both ? 3 : (Res ? 1 : (Msk ? 2 : 0));
+                const int ck = (d.act == MG_ACT_LRELU && !(d.slope >= 0.f && d.slope <= 1.f)) ? 3 : d.act;
+                if ((d.wide & 1) && ((ak == 0 && ck <= 2) || (ak <= 2 && ck == 0))) {
+                    auto body = [&](auto act_, auto aux_) {
+                        constexpr int ACT = decltype(act_)::value, AUX = decltype(aux_)::value;
+                        static_for<0, NT>([&](auto nt_) {
+                            constexpr int nt = decltype(nt_)::value;
+                            mark(2 + mt * 5 + nt);
+                            mg_f32x2_t v[8];
+#pragma unroll
+                            for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+                                for (int h2 = 0; h2 < 2; ++h2) {
+                                    mg_f32x2_t t = mg_pk(acc[mt][nt][rq * 4 + 2 * h2], acc[mt][nt][rq * 4 + 2 * h2 + 1])
+                                                 + mg_pk(bias4[rq][2 * h2], bias4[rq][2 * h2 + 1]);
+                                    if constexpr (AUX == 1) t += mg_pk(aux[nt][rq][2 * h2], aux[nt][rq][2 * h2 + 1]);
+                                    t = mg_act2<ACT>(t, neg);
+                                    if constexpr (AUX == 2) {
+                                        t[0] = aux[nt][rq][2 * h2] > 0.f ? t[0] : 0.f;
+                                        t[1] = aux[nt][rq][2 * h2 + 1] > 0.f ? t[1] : 0.f;
+                                    }
+                                    v[rq * 2 + h2] = t;
+                                }
+#pragma unroll
+                            for (int k2 = 0; k2 < 2; ++k2) {
+                                const uint4 w = mg_pair_swap(mg_pack_bf16x2x2(v[4 * k2], v[4 * k2 + 1]), mg_pack_bf16x2x2(v[4 * k2 + 2], v[4 * k2 + 3]));
+                                const int co = m0 + wm * MT * 32 + mt * 32 + k2 * 16 + hi * 8;
+                                if (pok[nt] && co < d.Cout) *reinterpret_cast<uint4*>(Out + opix[nt] + co) = w;
+                            }
+                        });
+                    };
+                    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+                    if (ak == 1) body(I0{}, I1{});
+                    else if (ak == 2) body(I0{}, I2{});
+                    else if (ck == 0) body(I0{}, I0{});
+                    else if (ck == 1) body(I1{}, I0{});
+                    else body(I2{}, I0{});
+                    return;
+                }
+            }
             static_for<0, NT>([&](auto nt_) {
                 constexpr int nt = decltype(nt_)::value;
+                mark(2 + mt * 5 + nt);
                 f32x4_t rv[4], mk[4];
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) { rv[rq] = aux[nt][rq]; mk[rq] = aux[nt][rq]; }
@@ -248,6 +315,14 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int occ = ((m0 + lrow) >> 1) + (hh * 2 + q) * 8 + hi * 4;
+                    if constexpr (sizeof(T) == 2) {
+                        if (have_xpre) {
+                            const uint2 r = xpre[(hh * NT + nt) * 2 + q];
+                            f32x4_t v = {__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+                            xall[hh][nt][q] = v;
+                            continue;
+                        }
+                    }
                     xall[hh][nt][q] = ET<T>::load4(X + xoff[nt] + (occ < d.Cout ? occ : 0));
                 }
         static_for<0, 2>([&](auto h_) {
@@ -274,6 +349,39 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
                         rstd4[q] = *reinterpret_cast<const f32x4_t*>(par + TM + TM / 2 + (lrow >> 1) + sub);
                     }
                     const int ocw = ((m0 + lrow) >> 1) + h * 16 + hi * 8;          // this lane's 8 consecutive channels after the exchange
+                    const int ck = (d.act == MG_ACT_LRELU && !(d.slope >= 0.f && d.slope <= 1.f)) ? 3 : d.act;
+                    // lean bodies: packed fp32 math, one per activation (see mg_act2); same operation order as the generic body below
+                    auto body = [&](auto act_) {
+                        constexpr int ACT = decltype(act_)::value;
+                        static_for<0, NT>([&](auto nt_) {
+                            constexpr int nt = decltype(nt_)::value;
+                            mg_f32x2_t g[2][2], hv[2][2];
+                            const mg_f32x2_t one = {1.f, 1.f};
+#pragma unroll
+                            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                                for (int h2 = 0; h2 < 2; ++h2) {
+                                    const int e = (h * 2 + q) * 4 + 2 * h2;
+                                    g[q][h2] = (one + mg_pk(acc[0][nt][e], acc[0][nt][e + 1])) + mg_pk(bg[q][2 * h2], bg[q][2 * h2 + 1]);
+                                    const mg_f32x2_t bt = mg_pk(acc[1][nt][e], acc[1][nt][e + 1]) + mg_pk(bb[q][2 * h2], bb[q][2 * h2 + 1]);
+                                    const mg_f32x2_t xh = (mg_pk(xv[nt][q][2 * h2], xv[nt][q][2 * h2 + 1]) - mg_pk(mean4[q][2 * h2], mean4[q][2 * h2 + 1]))
+                                                        * mg_pk(rstd4[q][2 * h2], rstd4[q][2 * h2 + 1]);
+                                    hv[q][h2] = mg_act2<ACT>(xh * g[q][h2] + bt, neg);
+                                }
+                            const uint4 hw = mg_pair_swap(mg_pack_bf16x2x2(hv[0][0], hv[0][1]), mg_pack_bf16x2x2(hv[1][0], hv[1][1]));
+                            uint4 gw = hw;
+                            if (G1) gw = mg_pair_swap(mg_pack_bf16x2x2(g[0][0], g[0][1]), mg_pack_bf16x2x2(g[1][0], g[1][1]));
+                            if (pok[nt] && ocw < d.Cout) {
+                                const size_t o = opix[nt] + ocw;
+                                *reinterpret_cast<uint4*>(Out + o) = hw;
+                                if (G1) *reinterpret_cast<uint4*>(G1 + o) = gw;
+                            }
+                        });
+                    };
+                    if (ck == 0) body(std::integral_constant<int, 0>{});
+                    else if (ck == 1) body(std::integral_constant<int, 1>{});
+                    else if (ck == 2) body(std::integral_constant<int, 2>{});
+                    else
                     static_for<0, NT>([&](auto nt_) {
                         constexpr int nt = decltype(nt_)::value;
                         f32x4_t g[2], hv[2];
@@ -331,12 +439,13 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
 // `pixmap(p, opix, upix)`: p = pixel index inside the workgroup's pixel tile (0 .. TN-1) -> false if the pixel does
 // not exist, else opix = flat output pixel index ((n*Hout + oy)*Wout + ox) and upix = the index of pixel (oy >> 1, ox >> 1)
 // in a half-resolution [N][Hout/2][Wout/2] tensor (used when d.x_up).
-template <typename T, int MT, int NT, int EPI, int TM, typename PixMap>
+template <typename T, int MT, int NT, int EPI, int TM, typename PixMap, typename Mark = EpiNoMark>
 __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT][NT], int m0, PixMap&& pixmap,
-                                              int wm, int wn, int l31, int hi, const float* par)
+                                              int wm, int wn, int l31, int hi, const float* par, Mark&& mark,
+                                              const uint2 (&xpre)[2 * NT * 2], bool have_xpre)
 {
     if (((d.Cout | d.Cout_gemm) & 3) == 0 && d.act != MG_ACT_TANH) {
-        conv_epilogue_fast<T, MT, NT, EPI, TM>(d, acc, m0, pixmap, wm, wn, l31, hi, par);
+        conv_epilogue_fast<T, MT, NT, EPI, TM>(d, acc, m0, pixmap, wm, wn, l31, hi, par, mark, xpre, have_xpre);
         return;
     }
     // ---- epilogue -----------------------------------------------------------
@@ -428,6 +537,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT
             });
         }
     });
+}
+
+template <typename T, int MT, int NT, int EPI, int TM, typename PixMap>
+__device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT][NT], int m0, PixMap&& pixmap,
+                                              int wm, int wn, int l31, int hi, const float* par)
+{
+    const uint2 none[2 * NT * 2] = {};
+    conv_epilogue<T, MT, NT, EPI, TM>(d, acc, m0, pixmap, wm, wn, l31, hi, par, EpiNoMark(), none, false);
 }
 
 // zero source for out-of-image taps / tail rows: long enough to be walked chunk by chunk (<= 8 KiB of K per tap: Cin <= 4096 bf16 / 2048 f32)

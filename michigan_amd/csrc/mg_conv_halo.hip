@@ -32,6 +32,7 @@
 #endif
 
 extern int g_mg_conv_halo_big;     // mg_set_option(4, v): 0 = never use the 128 x 16x16 geometry
+extern int g_mg_conv_dbg_noepi;    // mg_set_option(10, v): 0 product; 1 main loop only; 2..4 probes of the big tile (below)
 extern int g_mg_conv_halo_ring;    // mg_set_option(9, v): weight-slab ring depth of the 128 x 16x16 geometry (3 or 4)
 
 namespace {
@@ -73,7 +74,18 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsig
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-template <typename T, int EPI, int WM, int NT, int RING = 3>
+// PROBE (measurement builds of the big tile, mg_set_option(10, 2..4); results are WRONG, only the time / the stamps mean anything):
+//   1 = no weight stream after the prologue, 2 = no s_barrier, 3 = s_memtime stamps around the wait, the barrier and the tap
+__device__ unsigned long long* g_mg_probe_out = nullptr;     // PROBE 4: [workgroup][wave][4] stamps (mg_set_option(13 / 14, low / high half of a device address))
+
+__device__ __forceinline__ unsigned long long stamp()
+{
+    unsigned long long v;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory");
+    return v;
+}
+
+template <typename T, int EPI, int WM, int NT, int RING = 3, int PROBE = 0>
 __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(const ConvK d)
 {
     using G = HaloGeom<WM, NT, RING>;
@@ -87,6 +99,9 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
     constexpr int KX  = BF ? 32 : 16;                          // byte XOR that selects the lane's second K piece
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring RING x ASTAGE][patch 2 x PSTAGE][dump][params]
+    unsigned long long e_entry = 0;
+    if constexpr (PROBE == 4) e_entry = stamp();
+    if (d.wide & 8) __builtin_amdgcn_s_setprio(3);          // mg_set_option(15, 1): prologue and epilogue outrank the co-resident workgroup's main loop
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -241,6 +256,39 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
         }
     };
 
+    auto pixmap = [&](int p, size_t& opix, size_t& upix) -> bool {
+        const int py = p >> 4;
+        const int y = y0 + py, x = x0 + (((p & 15) - 2 * (py & 1)) & 15);
+        if (y >= d.Hout || x >= d.Wout) return false;
+        opix = (size_t)((img * d.Hout + y) * d.Wout + x);
+        upix = (size_t)((img * (d.Hout >> 1) + (y >> 1)) * (d.Wout >> 1) + (x >> 1));
+        return true;
+    };
+    // SPADE (bf16): the x quads the epilogue modulates are fetched HERE, ahead of every operand load, so they arrive in the shadow
+    // of the first patch instead of costing the epilogue its own trip to HBM with the matrix pipe idle behind it (the SPADE epilogue
+    // was 8.2 us of a 39 us workgroup, 6.3 us of it with the stores predicated off: profiles/r02_halo_probe.txt).  32 registers.
+    constexpr bool XPRE = EPI == MG_EPI_SPADE && BF;
+    uint2 xpre[2 * NT * 2] = {};
+    bool xpre_ok = false;
+    if constexpr (XPRE) {
+        xpre_ok = ((d.Cout | d.Cout_gemm) & 3) == 0 && d.act != MG_ACT_TANH;          // the batched epilogue will run
+        if (xpre_ok) {
+            const uint16_t* __restrict__ X = reinterpret_cast<const uint16_t*>(d.x);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                size_t opix, upix = 0;
+                const bool ok = pixmap(wn * NT * 32 + nt * 32 + l31, opix, upix);
+                const unsigned xo = ok ? (unsigned)((d.x_up ? upix : opix) * d.Cout) : 0u;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int occ = ((m0 + wm * 64) >> 1) + (hh * 2 + q) * 8 + hi * 4;
+                        xpre[(hh * NT + nt) * 2 + q] = *reinterpret_cast<const uint2*>(X + xo + (occ < d.Cout ? occ : 0));
+                    }
+            }
+        }
+    }
     // epilogue channel parameters (LDS-DMA, the oldest loads of each wave)
     float* const par = reinterpret_cast<float*>(smem + G::PAR);
     conv_stage_params_dma<TM_H, EPI, 4>(d, m0, lds0 + G::PAR, wave, lane);
@@ -249,7 +297,51 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
 #pragma unroll
     for (int i = 0; i < PF; ++i) issue_a(i, false);
 
-    if constexpr (RING == 3) {
+    unsigned long long e_begin = 0;
+    if constexpr (PROBE == 4) e_begin = stamp();
+    if (d.wide & 8) __builtin_amdgcn_s_setprio(0);
+    if constexpr (PROBE != 0 && PROBE != 4) {
+        unsigned long long t_wait = 0, t_bar = 0, t_tap = 0, t_all = stamp();
+        for (int c = 0; c < nchunk; ++c) {
+            const bool next_chunk = (c + 1 < nchunk);
+            const int pdelta = (c & 1) ? -PSTAGE : PSTAGE;
+            static_for<0, 9>([&](auto t_) {
+                constexpr int t = decltype(t_)::value;
+                unsigned long long s0 = 0, s1 = 0, s2 = 0;
+                if constexpr (PROBE == 3) s0 = stamp();
+                if constexpr (PROBE == 1) { if constexpr (t == 0) wait_vmcnt<0>(); }
+                else {
+                    if constexpr (t == 1 || t == 2) { if (next_chunk) wait_vmcnt<A_IPS + P_IPS>(); else wait_vmcnt<A_IPS>(); }
+                    else if constexpr (t == 8)      { if (next_chunk) wait_vmcnt<A_IPS>(); else wait_vmcnt<0>(); }
+                    else                            wait_vmcnt<A_IPS>();
+                }
+                if constexpr (PROBE == 3) s1 = stamp();
+                if constexpr (PROBE != 2) __builtin_amdgcn_s_barrier();
+                if constexpr (PROBE == 3) s2 = stamp();
+                if constexpr (PROBE != 1) {
+                    if constexpr (t < 7) issue_a((t + 2) % 3, t == 6);
+                    else { if (next_chunk) issue_a((t + 2) % 3, false); }
+                }
+                if constexpr (t == 0) { if (next_chunk) issue_patch((c + 1) & 1); }
+                compute(t_, t % 3);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) boff[t][nt] += pdelta;
+                if constexpr (PROBE == 3) {
+                    const unsigned long long s3 = stamp();
+                    t_wait += s1 - s0; t_bar += s2 - s1; t_tap += s3 - s2;
+                }
+            });
+        }
+        if constexpr (PROBE == 3) {
+            t_all = stamp() - t_all;
+            if (lane == 0) {
+                unsigned long long* o = reinterpret_cast<unsigned long long*>(d.out) + ((size_t)blockIdx.x * 4 + wave) * 4;
+                o[0] = t_wait; o[1] = t_bar; o[2] = t_tap; o[3] = t_all;
+            }
+            if (acc[0][0][0] == 12345.678f) reinterpret_cast<T*>(d.out)[1 << 20] = (T)1;      // keeps the MFMAs alive
+            return;
+        }
+    } else if constexpr (RING == 3) {
         for (int c = 0; c < nchunk; ++c) {
             const bool next_chunk = (c + 1 < nchunk);
             const int pdelta = (c & 1) ? -PSTAGE : PSTAGE;          // this tap's patch addresses for the next chunk
@@ -298,22 +390,32 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
         }
     }
 
-    auto pixmap = [&](int p, size_t& opix, size_t& upix) -> bool {
-        const int py = p >> 4;
-        const int y = y0 + py, x = x0 + (((p & 15) - 2 * (py & 1)) & 15);
-        if (y >= d.Hout || x >= d.Wout) return false;
-        opix = (size_t)((img * d.Hout + y) * d.Wout + x);
-        upix = (size_t)((img * (d.Hout >> 1) + (y >> 1)) * (d.Wout >> 1) + (x >> 1));
-        return true;
-    };
-    if (d.wide & 2) {                            // measurement aid (mg_set_option(10, 1)): main loop only; one store keeps the MFMAs alive
+    if (d.wide & 8) __builtin_amdgcn_s_setprio(3);
+    if (PROBE != 4 && (d.wide & 2)) {                            // measurement aid (mg_set_option(10, 1)): main loop only; one store keeps the MFMAs alive
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<T*>(d.out)[0] = (T)1;
         return;
     }
-    conv_epilogue<T, MT, NT, EPI, TM_H>(d, acc, m0, pixmap, wm, wn, l31, hi, par);
+    if constexpr (PROBE == 4) {
+        const unsigned long long e0 = stamp();
+        unsigned long long ts[12] = {};
+        conv_epilogue<T, MT, NT, EPI, TM_H>(d, acc, m0, pixmap, wm, wn, l31, hi, par, [&](int i) { ts[i] = stamp(); }, xpre, xpre_ok);
+        const unsigned long long e1 = stamp();
+        wait_vmcnt<0>();
+        const unsigned long long e2 = stamp();
+        if (lane == 0 && g_mg_probe_out) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+            unsigned long long* o = g_mg_probe_out + ((size_t)blockIdx.x * 4 + wave) * 20;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) o[8 + i] = ts[i];
+            o[0] = e_entry; o[1] = e_begin; o[2] = e0; o[3] = e1; o[4] = e2; o[5] = ((unsigned long long)xcc << 32) | hw;
+        }
+        return;
+    }
+    conv_epilogue<T, MT, NT, EPI, TM_H>(d, acc, m0, pixmap, wm, wn, l31, hi, par, EpiNoMark(), xpre, xpre_ok);
 }
 
-template <typename T, int EPI, int WM, int NT, int RING = 3>
+template <typename T, int EPI, int WM, int NT, int RING = 3, int PROBE = 0>
 int launch_halo_g(ConvK& k, hipStream_t st)
 {
     using G = HaloGeom<WM, NT, RING>;
@@ -323,7 +425,7 @@ int launch_halo_g(ConvK& k, hipStream_t st)
     const long nblk = (long)k.N * k.tiles_y * k.tiles_x * k.tiles_m;
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_taps(halo): bad grid %ld", nblk);
     static_assert(RING == 3 || 2 * G::LDS <= 160 * 1024, "LDS budget of the deep ring: two workgroups per CU");
-    auto kern = conv3x3_halo_kernel<T, EPI, WM, NT, RING>;
+    auto kern = conv3x3_halo_kernel<T, EPI, WM, NT, RING, PROBE>;
     if constexpr (G::LDS > 65536) {
         static bool attr_done = false;
         if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); attr_done = true; }
@@ -339,12 +441,25 @@ int launch_halo(ConvK& k, hipStream_t st)
     if (k.Cout_gemm <= 64) return launch_halo_g<T, EPI, 1, 2>(k, st);
     // 16x16-pixel tiles once they still give every CU its two workgroups at least twice over
     const long big = (long)k.N * ((k.Hin + 15) / 16) * ((k.Win + 15) / 16) * ((k.Cout_gemm + 127) / 128);
-    if (g_mg_conv_halo_big && k.Hin >= 16 && big >= 1024)
+    if (g_mg_conv_halo_big && k.Hin >= 16 && big >= 1024) {
+        if constexpr (sizeof(T) == 2) {
+            if (g_mg_conv_dbg_noepi == 2) return launch_halo_g<T, EPI, 2, 4, 3, 1>(k, st);
+            if (g_mg_conv_dbg_noepi == 3) return launch_halo_g<T, EPI, 2, 4, 3, 2>(k, st);
+            if (g_mg_conv_dbg_noepi == 4) return launch_halo_g<T, EPI, 2, 4, 3, 3>(k, st);
+            if (g_mg_conv_dbg_noepi >= 5) return launch_halo_g<T, EPI, 2, 4, 3, 4>(k, st);      // 6: ... with the stores predicated off
+        }
         return g_mg_conv_halo_ring == 4 ? launch_halo_g<T, EPI, 2, 4, 4>(k, st) : launch_halo_g<T, EPI, 2, 4, 3>(k, st);
+    }
     return launch_halo_g<T, EPI, 2, 2>(k, st);
 }
 
 }  // namespace
+
+int conv_halo_set_probe(unsigned long long addr)
+{
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(addr);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_mg_probe_out), &p, sizeof(p)) == hipSuccess ? MG_OK : MG_ERR_ARG;
+}
 
 int launch_conv_halo(ConvK& k, int dtype, int epilogue, hipStream_t st)
 {
