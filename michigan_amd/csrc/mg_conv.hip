@@ -23,7 +23,7 @@ int g_mg_conv_bigtiles = 1;      // allow the 128x256 / 256x256 tiles (mg_set_op
 extern int g_mg_wgrad3x3;          // mg_wgrad.hip (mg_set_option(3, v))
 extern int g_mg_conv_thin;         // mg_conv_thin.hip (mg_set_option(6, v))
 extern int g_mg_conv_dot;          // mg_conv_dot.hip (mg_set_option(8, v))
-int g_mg_conv_prio = 0;          // mg_set_option(15, v): halo kernel raises its wave priority outside the main loop
+int g_mg_conv_noxpre = 0;        // mg_set_option(15, 1): A/B switch, the SPADE halo kernel loads x in its epilogue instead of ahead of the main loop
 int g_mg_conv_dbg_noepi = 0;     // MEASUREMENT ONLY (mg_set_option(10, 1)): the halo kernel returns before its epilogue -- wrong results, main-loop time
 int g_mg_conv_wide = 1;          // bf16 epilogues store 16 bytes per lane after a half-wave quad exchange (mg_set_option(7, v))
 int g_mg_conv_pipeline = 1;      // 0 = register-staged double buffer, 1 = LDS-DMA 3-stage ring (mg_set_option(0, v))
@@ -564,7 +564,7 @@ extern "C" int mg_conv_taps(const mg_conv_desc* d, void* stream)
     k.x_up = d->epilogue == MG_EPI_SPADE ? d->x_up : 0;
     k.ngemm = d->N * d->Hj * d->Wj; k.tiles_m = 0; k.tpc = 1; k.tiles_y = k.tiles_x = 0;
     k.ksplit = 1; k.ntiles = 1; k.ws = nullptr;
-    k.wide = ((g_mg_conv_wide && d->dtype == MG_BF16 && (d->Cout % 8) == 0) ? 1 : 0) | (g_mg_conv_dbg_noepi ? 2 : 0) | (g_mg_conv_dbg_noepi == 6 ? 4 : 0) | (g_mg_conv_prio ? 8 : 0);
+    k.wide = ((g_mg_conv_wide && d->dtype == MG_BF16 && (d->Cout % 8) == 0) ? 1 : 0) | (g_mg_conv_dbg_noepi ? 2 : 0) | (g_mg_conv_dbg_noepi == 6 ? 4 : 0) | (g_mg_conv_noxpre ? 8 : 0);
     for (int t = 0; t < MG_MAX_TAPS; ++t)
         k.tap[t] = t < d->ntaps ? (int)((((uint32_t)(int)d->tap_dy[t]) & 0xffffu) | (((uint32_t)(int)d->tap_dx[t]) << 16)) : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -583,7 +583,7 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 7 && (value == 0 || value == 1)) { g_mg_conv_wide = value; return MG_OK; }
     if (key == 8 && (value == 0 || value == 1)) { g_mg_conv_dot = value; return MG_OK; }
     if (key == 9 && (value == 3 || value == 4)) { g_mg_conv_halo_ring = value; return MG_OK; }
-    if (key == 15 && (value == 0 || value == 1)) { g_mg_conv_prio = value; return MG_OK; }
+    if (key == 15 && (value == 0 || value == 1)) { g_mg_conv_noxpre = value; return MG_OK; }
     if (key == 13) { g_probe_lo = (unsigned)value; return MG_OK; }
     if (key == 14) return conv_halo_set_probe(((unsigned long long)(unsigned)value << 32) | g_probe_lo);
     if (key == 10 && value >= 0 && value <= 6) { g_mg_conv_dbg_noepi = value; return MG_OK; }

@@ -101,7 +101,6 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring RING x ASTAGE][patch 2 x PSTAGE][dump][params]
     unsigned long long e_entry = 0;
     if constexpr (PROBE == 4) e_entry = stamp();
-    if (d.wide & 8) __builtin_amdgcn_s_setprio(3);          // mg_set_option(15, 1): prologue and epilogue outrank the co-resident workgroup's main loop
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,13 +165,18 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
         wbase += last_tap ? chunkwrap : tapstride;
     };
 
+    // The product bf16 kernel never zeroes its accumulators: the first tap's first K step runs its MFMAs with a constant-zero C
+    // operand (128 v_mov per lane less in a prologue whose VALU issue competes with the co-resident workgroup's MFMA stream).
+    constexpr bool ZERO_C = BF && RING == 3 && (PROBE == 0 || PROBE == 4);
     f32x16_t acc[MT][NT];
+    if constexpr (!ZERO_C) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    }
 
     // LDS byte offsets (from smem) of this lane's operand pieces, K piece `ksp` (the other one is ^ KX):
     //   A: row wm*64 + l31 (+32 per mt) of the slot;   B: per tap and column tile, the shifted patch pixel
@@ -180,11 +184,10 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
     const int aoff = (wm * 64 + l31) * ROWB + ((ksp ^ ((l31 >> 2) & 3)) << 4);
     int boff[9][NT];
     {
-        const int tapv = d.tap[lane];
         const int py = l31 >> 4, px = (l31 - 2 * py) & 15;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int tp = __builtin_amdgcn_readlane(tapv, t);
+            const int tp = d.tap[t];                          // kernel argument: a scalar load, no trip through a vector register
             const int dy = (int)(short)(tp & 0xffff), dx = tp >> 16;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -194,8 +197,9 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
         }
     }
 
-    auto compute = [&](auto t_, int slot) {
+    auto compute = [&](auto t_, int slot, auto first_) {
         constexpr int t = decltype(t_)::value;
+        constexpr bool FIRST = decltype(first_)::value;          // very first K step of the workgroup: C = 0
         const unsigned char* As = smem + slot * ASTAGE;
         if constexpr (BF) {
 #pragma unroll
@@ -210,8 +214,13 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        if (FIRST && ks == 0) {
+                            const f32x16_t zero = {};
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], zero, 0, 0, 0);
+                        } else
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                    }
             }
 #if MG_HALO_SCHED == 1
             if constexpr (MT == 2 && NT == 4) {
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
     uint2 xpre[2 * NT * 2] = {};
     bool xpre_ok = false;
     if constexpr (XPRE) {
-        xpre_ok = ((d.Cout | d.Cout_gemm) & 3) == 0 && d.act != MG_ACT_TANH;          // the batched epilogue will run
+        xpre_ok = ((d.Cout | d.Cout_gemm) & 3) == 0 && d.act != MG_ACT_TANH && !(d.wide & 8);          // the batched epilogue will run (bit 3: A/B switch, mg_set_option(15, 1))
         if (xpre_ok) {
             const uint16_t* __restrict__ X = reinterpret_cast<const uint16_t*>(d.x);
 #pragma unroll
@@ -299,7 +308,6 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
 
     unsigned long long e_begin = 0;
     if constexpr (PROBE == 4) e_begin = stamp();
-    if (d.wide & 8) __builtin_amdgcn_s_setprio(0);
     if constexpr (PROBE != 0 && PROBE != 4) {
         unsigned long long t_wait = 0, t_bar = 0, t_tap = 0, t_all = stamp();
         for (int c = 0; c < nchunk; ++c) {
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
                     else { if (next_chunk) issue_a((t + 2) % 3, false); }
                 }
                 if constexpr (t == 0) { if (next_chunk) issue_patch((c + 1) & 1); }
-                compute(t_, t % 3);
+                compute(t_, t % 3, std::false_type{});
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) boff[t][nt] += pdelta;
                 if constexpr (PROBE == 3) {
@@ -338,11 +346,18 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
                 unsigned long long* o = reinterpret_cast<unsigned long long*>(d.out) + ((size_t)blockIdx.x * 4 + wave) * 4;
                 o[0] = t_wait; o[1] = t_bar; o[2] = t_tap; o[3] = t_all;
             }
-            if (acc[0][0][0] == 12345.678f) reinterpret_cast<T*>(d.out)[1 << 20] = (T)1;      // keeps the MFMAs alive
+            float keep = 0.f;                                                                  // keeps ALL the MFMAs alive
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) keep += acc[mt][nt][r];
+            if (keep == 12345.678f) reinterpret_cast<T*>(d.out)[1 << 20] = (T)1;
             return;
         }
     } else if constexpr (RING == 3) {
-        for (int c = 0; c < nchunk; ++c) {
+        auto chunk = [&](int c, auto first_) {
             const bool next_chunk = (c + 1 < nchunk);
             const int pdelta = (c & 1) ? -PSTAGE : PSTAGE;          // this tap's patch addresses for the next chunk
             static_for<0, 9>([&](auto t_) {
@@ -357,11 +372,13 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
                 if constexpr (t < 7) issue_a((t + 2) % 3, t == 6);
                 else { if (next_chunk) issue_a((t + 2) % 3, false); }
                 if constexpr (t == 0) { if (next_chunk) issue_patch((c + 1) & 1); }
-                compute(t_, t % 3);
+                compute(t_, t % 3, std::bool_constant<ZERO_C && decltype(first_)::value && t == 0>{});
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) boff[t][nt] += pdelta;
             });
-        }
+        };
+        chunk(0, std::true_type{});
+        for (int c = 1; c < nchunk; ++c) chunk(c, std::false_type{});
     } else {
         // RING 4: tap g = 9 c + t lives in slot g & 3 (9 = 1 mod 4, so the slot of tap t moves by one per chunk: a scalar).
         // Issue order per wave: ... W(g+1) W(g+2) | tap g: wait W(g), barrier, issue W(g+3) [, patch(c+1) at t = 0], compute.
@@ -382,7 +399,7 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
                 if constexpr (t < 6) issue_a((s0 + t + 3) & 3, t == 5);
                 else { if (next_chunk) issue_a((s0 + t + 3) & 3, false); }
                 if constexpr (t == 0) { if (next_chunk) issue_patch((c + 1) & 1); }
-                compute(t_, (s0 + t) & 3);
+                compute(t_, (s0 + t) & 3, std::false_type{});
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) boff[t][nt] += pdelta;
             });
@@ -390,7 +407,6 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
         }
     }
 
-    if (d.wide & 8) __builtin_amdgcn_s_setprio(3);
     if (PROBE != 4 && (d.wide & 2)) {                            // measurement aid (mg_set_option(10, 1)): main loop only; one store keeps the MFMAs alive
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<T*>(d.out)[0] = (T)1;
         return;
@@ -443,9 +459,11 @@ int launch_halo(ConvK& k, hipStream_t st)
     const long big = (long)k.N * ((k.Hin + 15) / 16) * ((k.Win + 15) / 16) * ((k.Cout_gemm + 127) / 128);
     if (g_mg_conv_halo_big && k.Hin >= 16 && big >= 1024) {
         if constexpr (sizeof(T) == 2) {
-            if (g_mg_conv_dbg_noepi == 2) return launch_halo_g<T, EPI, 2, 4, 3, 1>(k, st);
-            if (g_mg_conv_dbg_noepi == 3) return launch_halo_g<T, EPI, 2, 4, 3, 2>(k, st);
-            if (g_mg_conv_dbg_noepi == 4) return launch_halo_g<T, EPI, 2, 4, 3, 3>(k, st);
+            if constexpr (EPI == MG_EPI_PLAIN) {
+                if (g_mg_conv_dbg_noepi == 2) return launch_halo_g<T, EPI, 2, 4, 3, 1>(k, st);
+                if (g_mg_conv_dbg_noepi == 3) return launch_halo_g<T, EPI, 2, 4, 3, 2>(k, st);
+                if (g_mg_conv_dbg_noepi == 4) return launch_halo_g<T, EPI, 2, 4, 3, 3>(k, st);
+            }
             if (g_mg_conv_dbg_noepi >= 5) return launch_halo_g<T, EPI, 2, 4, 3, 4>(k, st);      // 6: ... with the stores predicated off
         }
         return g_mg_conv_halo_ring == 4 ? launch_halo_g<T, EPI, 2, 4, 4>(k, st) : launch_halo_g<T, EPI, 2, 4, 3>(k, st);

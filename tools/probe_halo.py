@@ -33,16 +33,26 @@ for name, cin, cout, hw, spade in SHAPES:
     res = {}
     with torch.no_grad():
         for rep in range(2):
-            be.mg_set_option(15, 1); be.mg_set_option(10, 0)
+            for pr in (1,):
+                be.mg_set_option(15, pr); be.mg_set_option(10, 0)
+                for _ in range(3): fn()
+                torch.cuda.synchronize()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(10): fn()
+                e.record(); torch.cuda.synchronize()
+                res.setdefault(f"prio{pr}", []).append(s.elapsed_time(e) / 10)
+            be.mg_set_option(15, 0)
+            be.mg_set_option(4, 0)
             for _ in range(3): fn()
             torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             for _ in range(10): fn()
             e.record(); torch.cuda.synchronize()
-            res.setdefault("prio", []).append(s.elapsed_time(e) / 10)
-            be.mg_set_option(15, 0)
-            for mode in (0, 1, 2, 3, 4):
+            res.setdefault("small", []).append(s.elapsed_time(e) / 10)
+            be.mg_set_option(4, 1)
+            for mode in ((0, 1) if spade else (0, 1, 2, 3, 4)):
                 be.mg_set_option(10, mode)
                 for _ in range(3): fn()
                 torch.cuda.synchronize()
@@ -51,7 +61,7 @@ for name, cin, cout, hw, spade in SHAPES:
                 for _ in range(10): fn()
                 e.record(); torch.cuda.synchronize()
                 res.setdefault(mode, []).append(s.elapsed_time(e) / 10)
-        be.mg_set_option(10, 4)
+        be.mg_set_option(10, 1 if spade else 4)
         out = fn(); torch.cuda.synchronize()
         probe = torch.zeros(nwg_of(n, hw, cout, spade) * 80, dtype=torch.int64, device="cuda")
         a = probe.data_ptr()
@@ -67,20 +77,22 @@ for name, cin, cout, hw, spade in SHAPES:
         be.mg_set_option(10, 0); be.mg_set_option(15, 0)
         be.mg_set_option(13, 0); be.mg_set_option(14, 0)
     t = {m: min(v) * 1e3 for m, v in res.items()}
+    for m in (2, 3, 4): t.setdefault(m, float('nan'))
     print(f"{name:24s} full {t[0]:7.1f} us {flops/t[0]/1e6:6.0f} TF/s | main loop {t[1]:7.1f} us {flops/t[1]/1e6:6.0f} TF/s"
-          f" | no weight stream {t[2]:7.1f} us | no barrier {t[3]:7.1f} us | stamped loop {t[4]:7.1f} us | full with s_setprio {t['prio']:7.1f} us", flush=True)
+          f" | no weight stream {t[2]:7.1f} us | no barrier {t[3]:7.1f} us | stamped loop {t[4]:7.1f} us | x loaded in the epilogue (spade) {t['prio1']:7.1f} us | 8x16-pixel tiles (3 workgroups per CU) {t['small']:7.1f} us", flush=True)
     nwg = n * (hw // 16) ** 2 * ((2 * cout if spade else cout) // 128)
-    st = out.contiguous().view(torch.uint8).flatten()[: nwg * 4 * 4 * 8].view(torch.int64).view(nwg, 4, 4).cpu().numpy().astype(np.float64)
-    per_tap = st[..., :3] / taps
-    tot = st[..., 3] / taps
-    print(f"    stamps per tap and wave (ticks of s_memrealtime (10 ns); {nwg} workgroups x 4 waves, {taps} taps): vmcnt wait {per_tap[..., 0].mean():6.1f}"
-          f"  barrier {per_tap[..., 1].mean():6.1f}  tap body {per_tap[..., 2].mean():6.1f}  loop total {tot.mean():6.1f}"
-          f"   (p10/p50/p90 of wait {np.percentile(per_tap[..., 0], [10, 50, 90]).round(1)}, barrier {np.percentile(per_tap[..., 1], [10, 50, 90]).round(1)},"
-          f" body {np.percentile(per_tap[..., 2], [10, 50, 90]).round(1)})", flush=True)
+    if not spade:
+        st = out.contiguous().view(torch.uint8).flatten()[: nwg * 4 * 4 * 8].view(torch.int64).view(nwg, 4, 4).cpu().numpy().astype(np.float64)
+        per_tap = st[..., :3] / taps
+        tot = st[..., 3] / taps
+        print(f"    stamps per tap and wave (ticks of s_memrealtime (10 ns); {nwg} workgroups x 4 waves, {taps} taps): vmcnt wait {per_tap[..., 0].mean():6.1f}"
+              f"  barrier {per_tap[..., 1].mean():6.1f}  tap body {per_tap[..., 2].mean():6.1f}  loop total {tot.mean():6.1f}"
+              f"   (p10/p50/p90 of wait {np.percentile(per_tap[..., 0], [10, 50, 90]).round(1)}, barrier {np.percentile(per_tap[..., 1], [10, 50, 90]).round(1)},"
+              f" body {np.percentile(per_tap[..., 2], [10, 50, 90]).round(1)})", flush=True)
     e6 = eps[6]
     print(f"    with the stores predicated off: main loop {np.mean(e6[..., 2] - e6[..., 1]):7.0f}  epilogue {np.mean(e6[..., 3] - e6[..., 2]):6.0f}", flush=True)
     e7 = eps[7]
-    print(f"    with s_setprio 3 outside the main loop: prologue {np.mean(e7[..., 1] - e7[..., 0]):6.0f}  main loop {np.mean(e7[..., 2] - e7[..., 1]):7.0f}  epilogue {np.mean(e7[..., 3] - e7[..., 2]):6.0f}", flush=True)
+    print(f"    with x loaded in the epilogue: prologue {np.mean(e7[..., 1] - e7[..., 0]):6.0f}  main loop {np.mean(e7[..., 2] - e7[..., 1]):7.0f}  epilogue {np.mean(e7[..., 3] - e7[..., 2]):6.0f}", flush=True)
     ep = eps[5]
     if not spade:
         ts = ep[..., 8:19].astype(np.float64)
