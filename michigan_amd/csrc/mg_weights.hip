@@ -36,10 +36,14 @@ __device__ __forceinline__ int row_to_co2(int r, int cout, bool two, int& which)
 // mode 1: 4*T floats per column), transposes through LDS (pitch T|1: conflict-free for T = 1, 9, 16, 49) and writes
 // 128-byte destination rows: every byte of W is read once.
 constexpr int PK_ROWS = 4, PK_COLS = 64, PK_MAXT = 49;
+// LDS: the 64 columns of a tile go through in sub-tiles of SC columns, SC = 64 for T <= 16 and 16 for the 7x7 window, so that the
+// buffer is 17 KiB instead of the 50 KiB a full 7x7 tile needs (one 7x7 layer in the table used to cap EVERY workgroup of the
+// launch at 3 per CU; with 8 per CU the 109 M generator weights re-pack in well under half the time, profiles/r02_pack_ab.txt).
+constexpr int PK_LDS_FLOATS = PK_ROWS * 64 * 17;                 // >= 4 x 64 x (16 | 1) and >= 4 x 16 x (49 | 1) = 3200
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const mg_pack_job* __restrict__ jobs, const int32_t* __restrict__ block_job)
 {
-    __shared__ float tile[PK_ROWS * PK_COLS * (PK_MAXT + 1)];
+    __shared__ float tile[PK_LDS_FLOATS];
     const mg_pack_job& j = jobs[block_job[blockIdx.x]];
     const int rel = (int)((int64_t)blockIdx.x - j.first_block);
     const int tid = threadIdx.x;
@@ -55,49 +59,58 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const mg_pack_job* __
     }
     const bool two = j.w1 != nullptr;
     const int T = j.taps, pitch = T | 1;
+    const int SC = T <= 16 ? 64 : 16;                            // sub-tile width (columns)
     const int cblocks = (j.cols_p + PK_COLS - 1) / PK_COLS;
-    const int r0 = (rel / cblocks) * PK_ROWS, c0 = (rel % cblocks) * PK_COLS;
+    const int r0 = (rel / cblocks) * PK_ROWS, cb0 = (rel % cblocks) * PK_COLS;
     const float sg = j.sigma ? j.sigma[0] : 1.f;
-    // ---- load: contiguous runs of the reference-layout source ----------------------------------------------------------------
-    if (j.mode == 0) {
-        const int ncol = min(PK_COLS, j.cin - c0);               // source columns (ci) that exist; the rest of the tile is zero padding
-        for (int rr = 0; rr < PK_ROWS; ++rr) {
-            int which = 0;
-            const int co = (r0 + rr < j.rows_p) ? row_to_co2(r0 + rr, j.cout, two, which) : -1;
-            const float* src = (co >= 0 && ncol > 0) ? (which ? j.w1 : j.w0) + ((size_t)co * j.cin + c0) * T : nullptr;
-            const int run = src ? ncol * T : 0;
-            int c = tid / T, t = tid - c * T;
-            const int dc = 256 / T, dt = 256 - dc * T;
-            for (int e = tid; e < PK_COLS * T; e += 256) {
-                tile[(rr * PK_COLS + c) * pitch + t] = e < run ? src[e] : 0.f;
-                c += dc; t += dt;
-                if (t >= T) { t -= T; ++c; }
+    // store mapping: 4 rows x (SC/2 column pairs) x (128/SC tap phases)
+    const int pairs = SC >> 1, nphase = 64 / pairs;
+    const int rr_s = tid >> 6, cp = ((tid & 63) % pairs) * 2, th = (tid & 63) / pairs;
+    for (int sc = 0; sc < PK_COLS; sc += SC) {
+        const int c0 = cb0 + sc;
+        if (c0 >= j.cols_p) break;                               // uniform
+        if (sc) __syncthreads();                                 // the previous sub-tile has been stored
+        // ---- load: contiguous runs of the reference-layout source --------------------------------------------------------------
+        if (j.mode == 0) {
+            const int ncol = max(0, min(SC, j.cin - c0));        // source columns (ci) that exist; the rest of the tile is zero padding
+            for (int rr = 0; rr < PK_ROWS; ++rr) {
+                int which = 0;
+                const int co = (r0 + rr < j.rows_p) ? row_to_co2(r0 + rr, j.cout, two, which) : -1;
+                const float* src = (co >= 0 && ncol > 0) ? (which ? j.w1 : j.w0) + ((size_t)co * j.cin + c0) * T : nullptr;
+                const int run = src ? ncol * T : 0;
+                int c = tid / T, t = tid - c * T;
+                const int dc = 256 / T, dt = 256 - dc * T;
+                for (int e = tid; e < SC * T; e += 256) {
+                    tile[(rr * SC + c) * pitch + t] = e < run ? src[e] : 0.f;
+                    c += dc; t += dt;
+                    if (t >= T) { t -= T; ++c; }
+                }
+            }
+        } else {
+            const int nrow = min(PK_ROWS, j.cin - r0);           // source rows (ci) that exist
+            const int per = PK_ROWS * T;                         // one column's contiguous run: W[co][r0 .. r0+3][0 .. T)
+            for (int e = tid; e < SC * per; e += 256) {
+                const int cc = e / per, rem = e - cc * per;
+                const int rr = rem / T, t = rem - rr * T;
+                int which = 0;
+                const int co = (c0 + cc < j.cols_p) ? row_to_co2(c0 + cc, j.cout, two, which) : -1;
+                float v = 0.f;
+                if (co >= 0 && rr < nrow) v = (which ? j.w1 : j.w0)[((size_t)co * j.cin + r0) * T + rem];
+                tile[(rr * SC + cc) * pitch + t] = v;
             }
         }
-    } else {
-        const int nrow = min(PK_ROWS, j.cin - r0);               // source rows (ci) that exist
-        const int per = PK_ROWS * T;                             // one column's contiguous run: W[co][r0 .. r0+3][0 .. T)
-        for (int e = tid; e < PK_COLS * per; e += 256) {
-            const int cc = e / per, rem = e - cc * per;
-            const int rr = rem / T, t = rem - rr * T;
-            int which = 0;
-            const int co = (c0 + cc < j.cols_p) ? row_to_co2(c0 + cc, j.cout, two, which) : -1;
-            float v = 0.f;
-            if (co >= 0 && rr < nrow) v = (which ? j.w1 : j.w0)[((size_t)co * j.cin + r0) * T + rem];
-            tile[(rr * PK_COLS + cc) * pitch + t] = v;
+        __syncthreads();
+        // ---- store: rows of consecutive destination columns (2 per thread) -------------------------------------------------------
+        const int r = r0 + rr_s, c = c0 + cp;
+        if (r < j.rows_p && c < j.cols_p) {                      // cols_p is even (a multiple of 8)
+            for (int t = th; t < T; t += nphase) {
+                float v0 = tile[(rr_s * SC + cp) * pitch + t], v1 = tile[(rr_s * SC + cp + 1) * pitch + t];
+                if (j.sigma) { v0 = v0 / sg; v1 = v1 / sg; }
+                const size_t o = ((size_t)t * j.rows_p + r) * j.cols_p + c;
+                if (j.dtype == MG_BF16) reinterpret_cast<uint32_t*>(j.dst)[o >> 1] = f2bf2(v0, v1);
+                else { float2 pv; pv.x = v0; pv.y = v1; *reinterpret_cast<float2*>(reinterpret_cast<float*>(j.dst) + o) = pv; }
+            }
         }
-    }
-    __syncthreads();
-    // ---- store: rows of 64 consecutive destination columns (2 per thread) ----------------------------------------------------------
-    const int rr = tid >> 6, cp = (tid & 31) * 2, th = (tid >> 5) & 1;          // 4 rows x 32 column pairs x 2 tap phases
-    const int r = r0 + rr, c = c0 + cp;
-    if (r >= j.rows_p || c >= j.cols_p) return;                                   // cols_p is even (a multiple of 8)
-    for (int t = th; t < T; t += 2) {
-        float v0 = tile[(rr * PK_COLS + cp) * pitch + t], v1 = tile[(rr * PK_COLS + cp + 1) * pitch + t];
-        if (j.sigma) { v0 = v0 / sg; v1 = v1 / sg; }
-        const size_t o = ((size_t)t * j.rows_p + r) * j.cols_p + c;
-        if (j.dtype == MG_BF16) reinterpret_cast<uint32_t*>(j.dst)[o >> 1] = f2bf2(v0, v1);
-        else { float2 p; p.x = v0; p.y = v1; *reinterpret_cast<float2*>(reinterpret_cast<float*>(j.dst) + o) = p; }
     }
 }
 
