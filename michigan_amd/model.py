@@ -15,6 +15,7 @@ Differences that do not change results (SURVEY.md section 8a "parity-preserving 
 from __future__ import annotations
 
 import argparse
+import os
 import math
 from typing import Dict
 
@@ -260,6 +261,8 @@ class Pix2PixModel(nn.Module):
                     own[key].copy_(val)
 
     def create_optimizers(self, opt, group=None):
+        if os.environ.get("MG_DP_NO_GRAD") == "1":           # measurement switch: no gradient all-reduce
+            group = None
         if opt.no_TTUR:
             betas, g_lr, d_lr = (opt.beta1, opt.beta2), opt.lr, opt.lr
         else:

@@ -35,6 +35,9 @@ ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = C.MG_ACT_NONE, C.MG_ACT_RELU, C.MG_ACT
 WGRAD_USE_TR = True
 # Process group used to synchronise batch-norm statistics (set by michigan_amd.parallel); None = local stats.
 SYNC_BN_GROUP = None
+# sync-BN all-reduces: async_op=True runs them on the process group's own stream (two cross-stream hops per collective, overlap with
+# the neighbouring conv), False enqueues them on the current stream (torch >= 2.8: no hop).  A/B: MG_SYNCBN_ASYNC=1.
+SYNC_BN_ASYNC = os.environ.get("MG_SYNCBN_ASYNC", "0") == "1"
 # Weight / bias gradients of convolutions whose parameters live in an optim.FlatAdam arena bypass autograd: the wgrad kernel
 # accumulates into the arena's persistent GEMM-order buffer and one batched launch per optimiser step drains it (optim.py).
 _LEGACY_WEIGHTS = os.environ.get("MG_LEGACY_WEIGHTS") == "1"      # A/B: per-layer pack / spectral norm / unpack paths (round-1 behaviour)
@@ -583,7 +586,7 @@ def batch_stats_begin(x: torch.Tensor, up: bool = False):
         work = None
         if SYNC_BN_GROUP is not None:
             import torch.distributed as dist
-            work = dist.all_reduce(sums, group=SYNC_BN_GROUP, async_op=True)
+            work = dist.all_reduce(sums, group=SYNC_BN_GROUP, async_op=SYNC_BN_ASYNC)
             _count_collective("syncbn_fwd")
             count *= dist.get_world_size(SYNC_BN_GROUP)
         return sums, work, count, c
@@ -709,7 +712,7 @@ class _SpadeFn(torch.autograd.Function):
         work = None
         if ctx.needs_input_grad[0] and SYNC_BN_GROUP is not None:
             import torch.distributed as dist
-            work = dist.all_reduce(sums, group=SYNC_BN_GROUP, async_op=True)    # overlaps with the gamma/beta conv's backward below
+            work = dist.all_reduce(sums, group=SYNC_BN_GROUP, async_op=SYNC_BN_ASYNC)    # overlaps with the gamma/beta conv's backward below
             _count_collective("syncbn_bwd")
         if ctx.needs_input_grad[1]:
             wt = pack_weight(w_gamma, w_beta, x.dtype, _roundup(actv.shape[3], 128), rows, 1)
@@ -805,7 +808,7 @@ class _SpadePairFn(torch.autograd.Function):
         work = None
         if need_x and SYNC_BN_GROUP is not None:
             import torch.distributed as dist
-            work = dist.all_reduce(sums, group=SYNC_BN_GROUP, async_op=True)         # both branches in ONE collective; overlaps with the convs below
+            work = dist.all_reduce(sums, group=SYNC_BN_GROUP, async_op=SYNC_BN_ASYNC)         # both branches in ONE collective; overlaps with the convs below
             _count_collective("syncbn_bwd")
         grads = [None] * 11
         for b, (dh, h, g1, actv, wg, wb, base) in enumerate(branches):

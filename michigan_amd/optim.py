@@ -18,6 +18,7 @@ path (1-channel heads, 3-channel image conv) are reduced one by one after backwa
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Iterable, List, Optional
 
 import torch
@@ -31,6 +32,10 @@ class _Slot:
     """One convolution's weight (+ bias) gradient in the GEMM-order arena."""
     __slots__ = ("index", "key", "w0", "w1", "b0", "b1", "taps", "rows", "cols", "cout", "cin", "off", "boff", "numel",
                  "nblocks", "first_block", "sn", "written", "bucket")
+
+
+# Gradient buckets on a side HIP stream (overlap with the rest of backward) or on the current stream.  A/B: MG_DP_GRAD_SIDE=1.
+GRAD_SIDE_STREAM = os.environ.get("MG_DP_GRAD_SIDE", "0") == "1"
 
 
 class FlatAdam:
@@ -282,7 +287,9 @@ class FlatAdam:
     def _all_reduce(self, chunk):
         from . import parallel
         parallel.COLLECTIVES["grad_bucket"] += 1
-        if chunk.is_cuda:
+        if chunk.is_cuda and not GRAD_SIDE_STREAM:
+            dist.all_reduce(chunk, group=self.group, async_op=False)        # on the current stream (torch >= 2.8), in issue order
+        elif chunk.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=chunk.device)
             self._stream.wait_stream(torch.cuda.current_stream(chunk.device))

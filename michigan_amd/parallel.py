@@ -7,9 +7,12 @@ sync_batchnorm/replicate.py:50-67): no per-forward parameter broadcast (0.63 GB 
 forward in the reference), no gather of outputs, no Python rendez-vous per norm layer.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by one link, so
-gradients go out as few, large buckets (default 64 MiB, fp32) -- 438 MB of generator gradients
-are 7 collectives -- launched in reverse parameter order as soon as every gradient of a bucket
-has been produced (autograd post-accumulate hooks), overlapping with the remaining backward.
+gradients go out as few, large buckets (default 64 MiB, fp32) -- 460 MB of generator gradients
+are 8 collectives -- issued as soon as every gradient of a bucket has been produced.  Every collective
+is enqueued on the compute stream by default: with forced one-rank collectives a second active
+stream (the process group's, or a side stream for the buckets) cost 3-6 ms per 71 ms step in
+cross-stream dependencies, more than the ring time it could hide (DESIGN.md section 4;
+MG_SYNCBN_ASYNC=1 / MG_DP_GRAD_SIDE=1 restore the overlapped forms for an A/B on a real node).
 """
 from __future__ import annotations
 
@@ -34,7 +37,7 @@ def init(group=None):
         ops.SYNC_BN_GROUP = None
         return None
     _GROUP = group if group is not None else dist.group.WORLD
-    ops.SYNC_BN_GROUP = _GROUP
+    ops.SYNC_BN_GROUP = None if os.environ.get("MG_DP_NO_SYNCBN") == "1" else _GROUP      # measurement switch
     return _GROUP
 
 
