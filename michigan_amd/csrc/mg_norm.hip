@@ -130,7 +130,17 @@ __global__ __launch_bounds__(256) void reduce_stage2(const float* __restrict__ p
     double a = 0.0;
     if (i < C2) {
         const float* p = partial + (size_t)g * nchunks * C2 + i;
-        for (int k = kk; k < nchunks; k += 8) a += (double)p[(size_t)k * C2];
+        // eight independent loads in flight per thread (the trip count is a runtime value: without the explicit batch the loop was a
+        // chain of ~64 dependent L2 round trips, 10.6 us per launch, 99 launches per step); same summation order as before
+        int k = kk;
+        for (; k + 56 < nchunks; k += 64) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = p[(size_t)(k + 8 * j) * C2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += (double)v[j];
+        }
+        for (; k < nchunks; k += 8) a += (double)p[(size_t)k * C2];
     }
     red[threadIdx.x] = a;
     __syncthreads();
