@@ -29,7 +29,9 @@ int g_mg_conv_wide = 1;          // bf16 epilogues store 16 bytes per lane after
 int g_mg_conv_pipeline = 1;      // 0 = register-staged double buffer, 1 = LDS-DMA 3-stage ring (mg_set_option(0, v))
 
 #include "mg_conv_common.h"
-int conv_halo_set_probe(unsigned long long addr);          // mg_conv_halo.hip (measurement builds)
+int conv_halo_set_probe(unsigned long long addr);
+int wgrad3x3_set_probe(unsigned long long addr);         // mg_wgrad3x3.hip (measurement build)
+int g_mg_wgrad3x3_probe = 0;       // mg_set_option(12, 1): stamped build of wgrad3x3_kernel<2, 2>          // mg_conv_halo.hip (measurement builds)
 static unsigned g_probe_lo = 0;
 #include <map>
 #include <mutex>
@@ -585,7 +587,8 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 9 && (value == 3 || value == 4)) { g_mg_conv_halo_ring = value; return MG_OK; }
     if (key == 15 && (value == 0 || value == 1)) { g_mg_conv_noxpre = value; return MG_OK; }
     if (key == 13) { g_probe_lo = (unsigned)value; return MG_OK; }
-    if (key == 14) return conv_halo_set_probe(((unsigned long long)(unsigned)value << 32) | g_probe_lo);
+    if (key == 14) { const unsigned long long a = ((unsigned long long)(unsigned)value << 32) | g_probe_lo; const int r = conv_halo_set_probe(a); return r != MG_OK ? r : wgrad3x3_set_probe(a); }
+    if (key == 12 && (value == 0 || value == 1)) { g_mg_wgrad3x3_probe = value; return MG_OK; }
     if (key == 10 && value >= 0 && value <= 6) { g_mg_conv_dbg_noepi = value; return MG_OK; }
     return mg_fail(MG_ERR_ARG, "mg_set_option: unknown key/value %d/%d", key, value);
 }

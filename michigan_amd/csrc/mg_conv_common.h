@@ -561,6 +561,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst)
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// global_load_lds with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst)      // 4 bytes per lane, lane i -> lds_dst + 4*i
 {
     unsigned keep;

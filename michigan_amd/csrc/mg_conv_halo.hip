@@ -62,18 +62,6 @@ template <int WM, int NT, int RING = 3> struct HaloGeom {
     static constexpr int OCC = NT == 4 ? 2 : 3;                 // waves per SIMD the register budget is set for
 };
 
-// global_load_lds with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset
-__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-
 // PROBE (measurement builds of the big tile, mg_set_option(10, 2..4); results are WRONG, only the time / the stamps mean anything):
 //   1 = no weight stream after the prologue, 2 = no s_barrier, 3 = s_memtime stamps around the wait, the barrier and the tap
 __device__ unsigned long long* g_mg_probe_out = nullptr;     // PROBE 4: [workgroup][wave][4] stamps (mg_set_option(13 / 14, low / high half of a device address))

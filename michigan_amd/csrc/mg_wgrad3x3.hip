@@ -16,13 +16,25 @@
 #include "mg_conv_common.h"
 #include "mg_wgrad_common.h"
 
+extern int g_mg_wgrad3x3_probe;    // mg_conv.hip, mg_set_option(12, v): 1 = launch the stamped build of wgrad3x3_kernel<2, 2>
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_p;
 
-template <int MT, int NT, bool W16>
+// Measurement build (mg_set_option(12, 1) + the stamp buffer of mg_set_option(13 / 14)): s_memrealtime stamps around the vmcnt wait,
+// the barrier, the DMA issue (address arithmetic included) and the MFMA block of every stage; tools/probe_wgrad3x3.py.
+__device__ unsigned long long* g_mg_wg3_probe_out = nullptr;
+__device__ __forceinline__ unsigned long long wg3_stamp()
+{
+    unsigned long long v;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory");
+    return v;
+}
+
+template <int MT, int NT, bool W16, bool PROBE = false>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wg3K d)
 {
     constexpr int TM = 64 * MT, TN = 64 * NT;
@@ -97,19 +109,57 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wg3K d)
     const int a_step = 32 * d.Cg * 2, x_step = 32 * d.Cin * 2;
     int sy, sx, sg_next = sbeg;                               // image row / column of the next stage to issue
     { const int rem = (sbeg * 32) % (H * W); sy = rem / W; sx = rem - sy * W; }
+    sy = __builtin_amdgcn_readfirstlane(sy); sx = __builtin_amdgcn_readfirstlane(sx);     // wave-uniform: the bounds tests of issue() stay scalar
+
+    // The DMA issue sits beside the other workgroup's MFMA stream, where a wave gets roughly one VALU issue per 10 cycles: with the
+    // bounds tests, selects and 64-bit adds done per lane it was 0.36 us of a 1.23 us stage (tools/probe_wgrad3x3.py).  Validity of a lane
+    // only depends on its CLASS (left halo column / right halo column / strip row) and on the wave-uniform strip position, so the lane
+    // classes become 64-bit ballots in scalar registers once, the per-stage test is scalar arithmetic, and a lane pays two adds and two
+    // v_cndmask (scalar mask operand) per X load; the dY loads take a scalar base + a constant per-lane offset (no VALU at all).
+    unsigned long long m_live[B_IPS], m_left[B_IPS], m_right[B_IPS], m_r1[B_IPS];
+#pragma unroll
+    for (int j = 0; j < B_IPS; ++j) {
+        const bool lv = brc[j] >= 0;
+        const int c = (brc[j] >> 4) - 1, r = brc[j] & 15;
+        m_live[j]  = __builtin_amdgcn_ballot_w64(lv);
+        m_left[j]  = __builtin_amdgcn_ballot_w64(lv && c == -1);
+        m_right[j] = __builtin_amdgcn_ballot_w64(lv && c == SEG);
+        m_r1[j]    = __builtin_amdgcn_ballot_w64(lv && r == 1);
+    }
+    const unsigned long long zaddr = (unsigned long long)(size_t)zsrc;
+    const unsigned zlo = (unsigned)zaddr, zhi = (unsigned)(zaddr >> 32);
 
     auto issue = [&](int stage) {
         const bool real = sg_next < send;
         const unsigned sbase = lds0 + stage * STAGE;
+        if (real) {
 #pragma unroll
-        for (int j = 0; j < A_IPS; ++j)
-            glds16(real ? abase + aoff[j] : zsrc, __builtin_amdgcn_readfirstlane(sbase + j * 4096 + wave * 1024));
+            for (int j = 0; j < A_IPS; ++j)
+                glds16_s(abase, (unsigned)aoff[j], __builtin_amdgcn_readfirstlane(sbase + j * 4096 + wave * 1024));
+        } else {
+#pragma unroll
+            for (int j = 0; j < A_IPS; ++j)
+                glds16(zsrc, __builtin_amdgcn_readfirstlane(sbase + j * 4096 + wave * 1024));
+        }
+        const int sxs = __builtin_amdgcn_readfirstlane(sx), sys = __builtin_amdgcn_readfirstlane(sy), kys = __builtin_amdgcn_readfirstlane(ky);
+        const bool lok = sxs > 0, rok = sxs + SEG < W;
+        const bool y0 = (unsigned)(sys + kys - 1) < (unsigned)H, y1 = (unsigned)(sys + kys) < (unsigned)H;
 #pragma unroll
         for (int j = 0; j < B_IPS; ++j) {
-            const int y = sy + (brc[j] & 15) + ky - 1, x = sx + (brc[j] >> 4) - 1;
-            const bool ok = real && brc[j] >= 0 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            unsigned long long v = real ? m_live[j] : 0ull;
+            if (!lok) v &= ~m_left[j];
+            if (!rok) v &= ~m_right[j];
+            if (W16) { if (!y0) v &= m_r1[j]; if (!y1) v &= ~m_r1[j]; }
+            else if (!y0) v = 0ull;
+            v = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);   // a scalar register pair for the mask operand
+            asm("" : "+s"(v));                                            // ... and never an immediate
+            const unsigned long long pa = (unsigned long long)(size_t)(xbase + boff[j]);
+            unsigned plo, phi;
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(plo) : "v"(zlo), "v"((unsigned)pa), "s"(v));
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(phi) : "v"(zhi), "v"((unsigned)(pa >> 32)), "s"(v));
             const bool live = (j * 4096 + wave * 1024) < B_BYTES;          // this wave's 1 KiB block lies inside the strip
-            glds16(ok ? xbase + boff[j] : zsrc, __builtin_amdgcn_readfirstlane(live ? sbase + A_BYTES + j * 4096 + wave * 1024 : dump));
+            glds16(reinterpret_cast<const void*>((size_t)(((unsigned long long)phi << 32) | plo)),
+                   __builtin_amdgcn_readfirstlane(live ? sbase + A_BYTES + j * 4096 + wave * 1024 : dump));
         }
         abase += a_step; xbase += x_step; ++sg_next;
         if (W16) { sy += 2; } else { sx += 32; if (sx >= W) { sx = 0; ++sy; } }
@@ -186,15 +236,25 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wg3K d)
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) issue(s);
     int slot = 0, islot = NS - 1;
+    unsigned long long t_wait = 0, t_bar = 0, t_issue = 0, t_mfma = 0, t_begin = 0;
+    if constexpr (PROBE) t_begin = wg3_stamp();
     for (int it = 0; it < nk; ++it) {
+        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        if constexpr (PROBE) s0 = wg3_stamp();
         wait_vmcnt<(NS - 2) * IPS>();
+        if constexpr (PROBE) s1 = wg3_stamp();
         __builtin_amdgcn_s_barrier();
+        if constexpr (PROBE) s2 = wg3_stamp();
         issue(islot);
+        if constexpr (PROBE) s3 = wg3_stamp();
         compute(slot);
+        if constexpr (PROBE) { const unsigned long long s4 = wg3_stamp(); t_wait += s1 - s0; t_bar += s2 - s1; t_issue += s3 - s2; t_mfma += s4 - s3; }
         slot = (slot == NS - 1) ? 0 : slot + 1;
         islot = (islot == NS - 1) ? 0 : islot + 1;
     }
     wait_vmcnt<0>();
+    unsigned long long t_loop_end = 0;
+    if constexpr (PROBE) t_loop_end = wg3_stamp();
 
     if (do_bias) {
 #pragma unroll
@@ -217,7 +277,15 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wg3K d)
                 atomicAdd(d.dw + ((size_t)(tap * d.Cg + co) * d.Cin + ci), acc[kx][mt][nt][r]);
         }
     });
+    if constexpr (PROBE) {
+        const unsigned long long t_end = wg3_stamp();
+        if (lane == 0 && g_mg_wg3_probe_out) {
+            unsigned long long* o = g_mg_wg3_probe_out + ((size_t)blockIdx.x * 4 + wave) * 8;
+            o[0] = t_wait; o[1] = t_bar; o[2] = t_issue; o[3] = t_mfma; o[4] = t_loop_end - t_begin; o[5] = t_end - t_loop_end; o[6] = (unsigned long long)nk; o[7] = t_begin;
+        }
+    }
 }
+
 
 template <int MT, int NT, bool W16>
 int launch3(Wg3K& k, hipStream_t st)
@@ -247,6 +315,16 @@ int launch3(Wg3K& k, hipStream_t st)
     auto kern = wgrad3x3_kernel<MT, NT, W16>;
     static bool attr_done = false;
     if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr_done = true; }
+    if constexpr (MT == 2 && NT == 2 && !W16) {
+        if (g_mg_wgrad3x3_probe) {
+            auto pk = wgrad3x3_kernel<MT, NT, W16, true>;
+            static bool pattr = false;
+            if (!pattr) { hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); pattr = true; }
+            hipLaunchKernelGGL(pk, dim3((unsigned)nblk), dim3(256), LDS, st, k);
+            MG_CHECK_LAUNCH("mg_conv_wgrad(3x3 probe)");
+            return MG_OK;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), LDS, st, k);
     MG_CHECK_LAUNCH("mg_conv_wgrad(3x3)");
     return MG_OK;
@@ -256,6 +334,12 @@ int launch3(Wg3K& k, hipStream_t st)
 
 // Eligibility is decided by the caller (mg_wgrad.hip): bf16, the 9 taps of a 3x3 / pad 1 window in raster
 // order, stride 1, Hin == Hj, Win == Wj, W == 16 or W % 32 == 0, H*W % 32 == 0, Cin >= 64 and Cg >= 64.
+int wgrad3x3_set_probe(unsigned long long addr)
+{
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(addr);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_mg_wg3_probe_out), &p, sizeof(p)) == hipSuccess ? MG_OK : MG_ERR_ARG;
+}
+
 int launch_wgrad3x3(Wg3K& k, hipStream_t st)
 {
     const bool m2 = k.Cg > 64, n2 = k.Cin > 64;
