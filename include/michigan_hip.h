@@ -398,8 +398,13 @@ int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* o
  * 6 = register-weight kernels for 3x3 convolutions over an 8-channel input (forward and weight gradient);
  * 7 = bf16 conv epilogues exchange channel quads between the two half-waves (v_permlane32_swap) and store 16 bytes per lane;
  * 8 = wave-per-pixel dot-product kernel for convolutions with <= 4 output channels over >= 128 input channels (the discriminators' heads).
+ * 9 = weight-slab ring depth of the big halo tile (3 default, or 4); 15 = 1: the SPADE halo kernel loads x in its epilogue instead of
+ * ahead of its K loop (default 0).
  * Results agree within accumulation-order rounding whatever the setting (each setting is bit-reproducible except
- * the weight gradients, which use fp32 atomics). */
+ * the weight gradients, which use fp32 atomics).
+ * MEASUREMENT builds (wrong or no results, timing only; tools/probe_halo.py, tools/probe_wgrad3x3.py): key 10 = 1..6 variants of the big
+ * halo tile (K loop only / no weight stream / no barrier / per-tap stamps / per-phase stamps / stores off), 12 = 1 stamped build of the
+ * 3x3 weight-gradient kernel, 13 and 14 = low and high half of the device address the stamps go to.  All default 0. */
 int         mg_set_option(int32_t key, int32_t value);
 
 /* sizeof(mg_conv_desc) (which=0) / sizeof(mg_wgrad_desc) (which=1): lets a
