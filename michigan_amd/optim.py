@@ -348,7 +348,12 @@ class FlatAdam:
                 torch.cuda.current_stream().wait_stream(self._stream)
             if scatter is not None:
                 views, buf = scatter
-                torch._foreach_copy_(views, list(buf.split([v.numel() for v in views])))
+                pieces = list(buf.split([v.numel() for v in views]))
+                if hasattr(torch, "_foreach_copy_"):
+                    torch._foreach_copy_(views, pieces)              # a few batched launches
+                else:
+                    for v, b in zip(views, pieces):
+                        v.copy_(b)
         self.drain_grads()
 
     # ---- checkpointing ----------------------------------------------------------------------
