@@ -25,6 +25,9 @@ import torch.nn as nn
 from . import inputs, networks, parallel
 from .optim import FlatAdam
 
+# generator step: D on the fake half with a graph, on the real half without (see Pix2PixModel.discriminate).  A/B: MG_STACKED_D=1.
+SPLIT_D_IN_G_STEP = os.environ.get("MG_STACKED_D", "0") != "1"
+
 
 def default_options(**over) -> argparse.Namespace:
     """Option namespace = options/base_options.py + train_options.py defaults + the README training flags."""
@@ -151,14 +154,35 @@ class Pix2PixModel(nn.Module):
         return self.netG(d["input_ref"], orient_mask=d["orient"], image_ref=d["image_ref"],
                          input_tag=d["input_tag"], noise=d["noise"], image_tag=d["image_tag"])
 
-    def discriminate(self, d, fake_image):
+    def discriminate(self, d, fake_image, split=False):
         """D([tag one-hot | orientation | image]) on fake and real stacked along the batch
         (pix2pix_model.py:546-594).  The 7-channel input is assembled directly in the kernels' NHWC layout
-        (+1 zero channel so that a pixel is 16 bytes) instead of an NCHW concat followed by a transpose."""
+        (+1 zero channel so that a pixel is 16 bytes) instead of an NCHW concat followed by a transpose.
+
+        split=True (the generator step): nothing flows back into the real half there -- the feature-matching target is detached
+        and the GAN term only reads pred_fake (pix2pix_model.py:273-300) -- yet a stacked pass makes every backward kernel of D
+        walk 2N samples whose second half carries zero gradients.  So the fake half runs alone with a graph (and the step's one
+        power iteration), then the real half under no_grad with D in eval mode: the spectral norm re-uses the u, v the first
+        pass just updated (sigma = u.W v either way) and there is no dropout / running statistic in D (InstanceNorm), so the
+        outputs are the stacked pass's outputs."""
         from . import ops
         dt = fake_image.dtype
         n, _, h, w = fake_image.shape
         cond = torch.cat([d["input_tag"], self.orientation_planes(d)], dim=1)                 # [N,4,H,W] fp32
+        if split and SPLIT_D_IN_G_STEP:
+            fin = torch.empty((n, h, w, 8), dtype=dt, device=fake_image.device)
+            fin = ops.assemble_nhwc8(fin, 0, cond, fake_image.permute(0, 2, 3, 1), cf=3)
+            pred_fake = self.netD(fin.permute(0, 3, 1, 2))
+            rin = torch.empty((n, h, w, 8), dtype=dt, device=fake_image.device)
+            ops.assemble_nhwc8(rin, 0, torch.cat([cond, d["image_tag"]], dim=1))
+            was_training = self.netD.training
+            self.netD.eval()
+            try:
+                with torch.no_grad():
+                    pred_real = self.netD(rin.permute(0, 3, 1, 2))
+            finally:
+                self.netD.train(was_training)
+            return pred_fake, pred_real
         both = torch.empty((2 * n, h, w, 8), dtype=dt, device=fake_image.device)
         ops.assemble_nhwc8(both, n, torch.cat([cond, d["image_tag"]], dim=1))                  # real half: all planar, no gradient
         both = ops.assemble_nhwc8(both, 0, cond, fake_image.permute(0, 2, 3, 1), cf=3)         # fake half: the generator's NHWC image
@@ -195,7 +219,7 @@ class Pix2PixModel(nn.Module):
         d = self._maybe_inpaint(d)
         pending = self._ref_is_tag_async(d)
         fake = self.generate_fake(d)
-        pred_fake, pred_real = self.discriminate(d, fake)
+        pred_fake, pred_real = self.discriminate(d, fake, split=True)
         label = d["input_tag"][:, 1:2]
         if not self.opt.no_gan_loss:
             losses["GAN"] = self.criterionGAN(pred_fake, True, for_discriminator=False, label=label)
