@@ -319,6 +319,9 @@ class Pix2PixTrainer:
             p.requires_grad_(flag)
 
     def run_generator_one_step(self, data):
+        # a new step: the generator's input-only pyramids are rebuilt (they are re-used only by this step's second generator pass,
+        # never across steps -- a benchmark that feeds the same synthetic batch every step must not get them for free)
+        getattr(self.pix2pix_model.netG, "__dict__", {}).pop("_mg_input_cache", None)
         self.optimizer_G.zero_grad()
         self._set_d_requires_grad(False)
         try:
