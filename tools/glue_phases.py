@@ -48,3 +48,15 @@ rows = sorted([r for r in rows if r[0] > 0], key=lambda r: -r[0])
 print("generate_fake (no_grad) by op and shape:")
 for dt, cnt, key, shp in rows[:60]:
     print(f"  {dt/1e3:6.3f} ms {cnt:3d}  {key:26s} {shp}")
+
+tr.optimizer_G.zero_grad(); tr._set_d_requires_grad(False)
+g_losses, _ = m(data, mode="generator")
+loss = sum(g_losses.values()).mean()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    loss.backward(); torch.cuda.synchronize()
+tr._set_d_requires_grad(True)
+rows = [(getattr(e, "self_device_time_total", 0) or 0, e.count, e.key, str(e.input_shapes)[:150]) for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::")]
+rows = sorted([r for r in rows if r[0] > 0], key=lambda r: -r[0])
+print("generator-step backward by op and shape:")
+for dt, cnt, key, shp in rows[:45]:
+    print(f"  {dt/1e3:6.3f} ms {cnt:3d}  {key:26s} {shp}")
