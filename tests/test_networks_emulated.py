@@ -68,3 +68,38 @@ def test_inference_config0_matches_reference_golden(emulator_backend):
     assert res["out_padded"].shape == gold["out_padded"].shape
     assert np.abs(res["out_padded"] - gold["out_padded"]).max() < 5e-5
     assert np.abs(res["out"] - gold["out"]).max() < 5e-5
+
+
+def test_split_discriminator_pass_equals_stacked_pass(emulator_backend):
+    """Generator step: D on the fake half with a graph + on the real half under no_grad in eval mode (model.discriminate(split=True))
+    gives the stacked pass's predictions, the same spectral-norm state afterwards, and the same gradient w.r.t. the fake image."""
+    import copy
+    import random
+    import michigan_amd.model as M
+    from michigan_amd.synth import synth_batch
+    import parity_utils as PU
+    torch.manual_seed(3)
+    opt = PU.small_opt(ngf=8, ndf=8, crop_size=64, random_expand_mask=False)
+    model_a = M.Pix2PixModel(opt)
+    model_b = copy.deepcopy(model_a)
+    data = synth_batch(2, 64, seed=5)
+    outs = {}
+    for name, model, split in (("stacked", model_a, False), ("split", model_b, True)):
+        random.seed(1)
+        d = model.preprocess_input(data)
+        fake = torch.tanh(torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(9))).requires_grad_(True)
+        for p in model.netD.parameters():
+            p.requires_grad_(False)
+        pf, pr = model.discriminate(d, fake, split=split)
+        loss = sum(t.float().mean() for p in pf for t in p) + sum((a.float() - b.float().detach()).abs().mean() for p, q in zip(pf, pr) for a, b in zip(p, q))
+        loss.backward()
+        outs[name] = ([t.detach().float() for p in pf for t in p], [t.detach().float() for p in pr for t in p], fake.grad.clone(),
+                      {k: v.clone() for k, v in model.netD.state_dict().items() if k.endswith("weight_u") or k.endswith("weight_v")})
+    a, b = outs["stacked"], outs["split"]
+    for x, y in zip(a[0] + a[1], b[0] + b[1]):
+        assert x.shape == y.shape
+        assert (x - y).abs().max().item() <= 1e-5 * max(1.0, x.abs().max().item())
+    assert (a[2] - b[2]).abs().max().item() <= 1e-5 * max(1e-6, a[2].abs().max().item()) + 1e-9
+    assert a[3].keys() == b[3].keys() and len(a[3]) > 0
+    for k in a[3]:
+        assert torch.allclose(a[3][k], b[3][k], rtol=1e-6, atol=1e-7), k
