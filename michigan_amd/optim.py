@@ -34,8 +34,10 @@ class _Slot:
                  "nblocks", "first_block", "sn", "written", "bucket")
 
 
-# Gradient buckets on a side HIP stream (overlap with the rest of backward) or on the current stream.  A/B: MG_DP_GRAD_SIDE=1.
-GRAD_SIDE_STREAM = os.environ.get("MG_DP_GRAD_SIDE", "0") == "1"
+# Where the gradient buckets are reduced.  2 (default): asynchronously on the process group's own stream -- overlaps the rest of
+# backward, measured at no fixed cost with one rank; 0: on the compute stream; 1: on an extra side HIP stream (+1 ms per step of
+# cross-stream dependencies with one rank).  A/B: MG_DP_GRAD_SIDE.
+GRAD_SIDE_STREAM = int(os.environ.get("MG_DP_GRAD_SIDE", "2"))        # 0 compute stream, 1 side stream, 2 the process group's stream
 
 
 class FlatAdam:
@@ -287,7 +289,9 @@ class FlatAdam:
     def _all_reduce(self, chunk):
         from . import parallel
         parallel.COLLECTIVES["grad_bucket"] += 1
-        if chunk.is_cuda and not GRAD_SIDE_STREAM:
+        if chunk.is_cuda and GRAD_SIDE_STREAM == 2:
+            self._work.append(dist.all_reduce(chunk, group=self.group, async_op=True))     # the process group's own stream, no extra side stream
+        elif chunk.is_cuda and not GRAD_SIDE_STREAM:
             dist.all_reduce(chunk, group=self.group, async_op=False)        # on the current stream (torch >= 2.8), in issue order
         elif chunk.is_cuda:
             if self._stream is None:

@@ -8,11 +8,11 @@ forward in the reference), no gather of outputs, no Python rendez-vous per norm 
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by one link, so
 gradients go out as few, large buckets (default 64 MiB, fp32) -- 460 MB of generator gradients
-are 8 collectives -- issued as soon as every gradient of a bucket has been produced.  Every collective
-is enqueued on the compute stream by default: with forced one-rank collectives a second active
-stream (the process group's, or a side stream for the buckets) cost 3-6 ms per 71 ms step in
-cross-stream dependencies, more than the ring time it could hide (DESIGN.md section 4;
-MG_SYNCBN_ASYNC=1 / MG_DP_GRAD_SIDE=1 restore the overlapped forms for an A/B on a real node).
+are 8 collectives -- issued as soon as every gradient of a bucket has been produced, asynchronously on
+the process group's stream (they overlap the rest of backward; no measurable fixed cost with one rank).
+The ~42 small sync-BN reductions of a step go on the compute stream instead: on the process group's
+stream each costs two cross-stream dependencies (3.2 ms per step with one rank), about the latency it
+could hide (MG_SYNCBN_ASYNC=1 / MG_DP_GRAD_SIDE=0|1 select the other forms).
 """
 from __future__ import annotations
 
