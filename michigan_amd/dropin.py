@@ -22,6 +22,7 @@ reference's other generators still use the NCHW originals.
 from __future__ import annotations
 
 import importlib
+import os
 import sys
 from typing import Dict, Optional, Tuple
 
@@ -55,12 +56,51 @@ def _set(modname: str, attr: str, value):
 _MISSING = object()
 
 
-def install(compute_dtype: Optional[str] = "fp32", losses: bool = True, data_parallel: bool = True) -> Dict[str, type]:
+def init_distributed(backend: Optional[str] = None) -> bool:
+    """Under a launcher that starts one process per GPU (`torchrun --nproc-per-node 8 train.py ...`: RANK / WORLD_SIZE /
+    LOCAL_RANK / MASTER_* in the environment) join the job: pin this process to its GPU and create the default process
+    group (backend "nccl" = RCCL on ROCm; gloo without a GPU).  Returns True when the process is a rank of a job.
+
+    The reference selects its device with `torch.cuda.set_device(opt.gpu_ids[0])` from the command line
+    (options/base_options.py:228-235), which is the same for every rank of a torchrun job.  So, as long as the HIP runtime has
+    not been initialised yet, the process narrows HIP_VISIBLE_DEVICES to its LOCAL_RANK-th device: `--gpu_ids 0` then means
+    "my GPU" on every rank and the reference needs no edit beyond `dropin.install()`.  MG_DROPIN_PIN_DEVICE=0 leaves the
+    environment alone (then pass the device yourself)."""
+    import torch.distributed as dist
+    if not dist.is_available():
+        return False
+    if dist.is_initialized():
+        return dist.get_world_size() > 1
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
+        return False
+    if int(os.environ["WORLD_SIZE"]) < 2 and os.environ.get("MG_DP_FORCE") != "1":
+        return False
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MG_DROPIN_PIN_DEVICE", "1") != "0" and not torch.cuda.is_initialized():
+        visible = [d for d in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if d != ""]
+        if len(visible) != 1:                                   # not pinned by the launcher already
+            os.environ["HIP_VISIBLE_DEVICES"] = visible[local] if visible else str(local)
+        local = 0
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC (this host driver supports nothing else)
+    has_gpu = torch.cuda.is_available()
+    if has_gpu:
+        torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    dist.init_process_group(backend or ("nccl" if has_gpu else "gloo"))
+    return True
+
+
+def install(compute_dtype: Optional[str] = "fp32", losses: bool = True, data_parallel: bool = True,
+            distributed: bool = True) -> Dict[str, type]:
     """Patch the HIP classes into the reference's `models.networks` package (which must be importable: the
     reference's root on sys.path).  `compute_dtype`: activation dtype of the patched networks ("fp32" | "bf16").
     `losses=False` keeps the reference's loss classes (they then consume the HIP networks' NCHW outputs with ATen ops).
-    `data_parallel=False` keeps the reference's nn.DataParallel wrapper.  Returns {name: patched class}.  Idempotent."""
+    `data_parallel=False` keeps the reference's nn.DataParallel wrapper.  `distributed`: join the torchrun job this process
+    was started in, if any (`init_distributed`); the patched `DataParallelWithCallback` then makes the reference trainer data
+    parallel over the ranks.  Returns {name: patched class}.  Idempotent."""
     global _INSTALLED
+    if distributed and data_parallel:
+        init_distributed()
     dtype = _DTYPES[compute_dtype]
     try:
         ref_base = importlib.import_module("models.networks.base_network").BaseNetwork

@@ -263,12 +263,18 @@ class Pix2PixModel(nn.Module):
         return os.path.join(self.opt.checkpoints_dir, self.opt.name, "%s_net_%s.pth" % (epoch, label))
 
     def save(self, epoch):
-        """`<epoch>_net_G.pth` / `<epoch>_net_D.pth`: plain state_dicts with the reference's keys, loadable by the reference."""
+        """`<epoch>_net_G.pth` / `<epoch>_net_D.pth`: plain state_dicts with the reference's keys, loadable by the reference.
+        Data parallel: rank 0 writes (temporary file + rename, so a reader never sees a torn file), everyone waits."""
         import os
-        os.makedirs(os.path.join(self.opt.checkpoints_dir, self.opt.name), exist_ok=True)
-        for label, net in (("G", self.netG), ("D", self.netD)):
-            if net is not None:
-                torch.save({k: v.detach().cpu() for k, v in net.state_dict().items()}, self._ckpt_path(label, epoch))
+        if parallel.rank() == 0:
+            os.makedirs(os.path.join(self.opt.checkpoints_dir, self.opt.name), exist_ok=True)
+            for label, net in (("G", self.netG), ("D", self.netD)):
+                if net is not None:
+                    path = self._ckpt_path(label, epoch)
+                    torch.save({k: v.detach().cpu() for k, v in net.state_dict().items()}, path + ".tmp")
+                    os.replace(path + ".tmp", path)
+        if parallel.grad_group() is not None:
+            torch.distributed.barrier(group=parallel.grad_group())
 
     def load(self, epoch):
         """util.load_network semantics: copy by key, skip unknown keys, strip a leading 'module.' (multi-GPU files).  The
@@ -276,8 +282,10 @@ class Pix2PixModel(nn.Module):
         import os
         for label, net in (("G", self.netG), ("D", self.netD)):
             path = self._ckpt_path(label, epoch)
-            if net is None or not os.path.exists(path):
+            if net is None:
                 continue
+            if not os.path.exists(path):                       # util.load_network raises too (torch.load on a missing file)
+                raise FileNotFoundError("checkpoint %s does not exist" % path)
             own = net.state_dict()
             for key, val in torch.load(path, map_location="cpu").items():
                 key = key[7:] if key.startswith("module.") else key

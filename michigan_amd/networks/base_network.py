@@ -15,6 +15,24 @@ class BaseNetwork(nn.Module):
     def modify_commandline_options(parser, is_train):
         return parser
 
+    # per-process caches living in the instance __dict__ (ctypes tables, weak references): never pickled / deep-copied
+    _TRANSIENT = ("_mg_input_cache", "_mg_spectral_plan")
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for k in self._TRANSIENT:
+            state.pop(k, None)
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in self._TRANSIENT:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     def set_compute_dtype(self, dtype):
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")

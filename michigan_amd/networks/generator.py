@@ -72,9 +72,13 @@ class SPADEBGenerator(BaseNetwork):
         # the same batch (generator step, then under no_grad for the discriminator step): the second pass re-uses them (~50 small
         # launches) when it is handed the very same tensor objects, unmodified (identity through weak references + version counters).
         src = (input_tag, orient_mask)
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in src if t is not None) + (dt, bool(opt.no_orientation), bool(opt.use_ig))
-        hit = self.__dict__.get("_mg_input_cache")
-        if INPUT_CACHE and hit is not None and hit[0] == key and all(r() is t for r, t in zip(hit[1], src) if t is not None):
+        # inference tensors have no version counter (torch.inference_mode): they bypass the cache
+        cacheable = INPUT_CACHE and not any(t is not None and t.is_inference() for t in src)
+        key = hit = None
+        if cacheable:
+            key = tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in src if t is not None) + (dt, bool(opt.no_orientation), bool(opt.use_ig))
+            hit = self.__dict__.get("_mg_input_cache")
+        if hit is not None and hit[0] == key and all(r() is t for r, t in zip(hit[1], src) if t is not None):
             pyramid, hair_masks = hit[2], hit[3]
         else:
             seg = input_tag
@@ -90,7 +94,8 @@ class SPADEBGenerator(BaseNetwork):
             pyramid = SegPyramid(seg, dt)
             hh, hw = hair.shape[2], hair.shape[3]
             hair_masks = [F.interpolate(hair, size=(int(hh / d), int(hw / d)), mode="nearest") for d in (8, 4, 2)] + [hair]
-            self.__dict__["_mg_input_cache"] = (key, tuple(weakref.ref(t) for t in src if t is not None), pyramid, hair_masks)
+            if cacheable:
+                self.__dict__["_mg_input_cache"] = (key, tuple(weakref.ref(t) for t in src if t is not None), pyramid, hair_masks)
 
         back_feats, back_masks = self.backgroud_enc(image_tag, input_tag, noise)
 

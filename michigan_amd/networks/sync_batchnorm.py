@@ -78,16 +78,53 @@ class SynchronizedBatchNorm2d(nn.Module):
 
 
 class DataParallelWithCallback(nn.Module):
-    """The name the reference trainer imports (pix2pix_trainer.py:6,21-24): exposes `.module` and forwards calls --
-    nothing else.  Data parallelism here is one PROCESS per GPU: cross-rank batch-norm statistics are switched on by
-    `michigan_amd.parallel.init()` (ops.SYNC_BN_GROUP) and gradient averaging belongs to the optimiser
-    (`michigan_amd.optim.FlatAdam(group=...)`, bucketed in-place all-reduce from post-accumulate hooks), so there is no
-    replication, scatter or gather for this wrapper to do; `device_ids` is accepted and ignored beyond its first entry."""
+    """The name the reference trainer imports (pix2pix_trainer.py:6,21-24).  Exposes `.module`, forwards calls, and -- when the
+    process is one rank of a torch.distributed job (`torchrun --nproc-per-node 8 train.py ...`) -- makes the wrapped model data
+    parallel the process-per-GPU way, which is everything nn.DataParallel + the replicate callback did for the reference
+    (sync_batchnorm/replicate.py:50-67, batchnorm.py:105-126) minus the per-forward work:
+
+      * `michigan_amd.parallel.init()`: cross-rank batch-norm statistics inside the sync-BN layers (ops.SYNC_BN_GROUP, its own
+        RCCL communicator) instead of the master/slave thread pipe;
+      * ONE broadcast of rank 0's parameters and buffers here (the reference re-broadcasts 0.63 GB per replica per forward);
+      * gradient averaging attached to whatever optimisers `module.create_optimizers(opt)` hands back afterwards (the
+        reference trainer calls it right after wrapping, pix2pix_trainer.py:29-33): `parallel.GradAverager` buckets for a
+        torch.optim optimiser, the arena's own in-place reduction for `optim.FlatAdam` -- equal to the reference's reduce-to-GPU-0
+        + mean over replicas, since d(mean_r L_r)/dtheta = mean_r dL_r/dtheta.
+
+    There is no scatter / gather: every rank feeds its own share of the global batch (its own loader shard) and keeps its own
+    losses; `device_ids` is accepted for signature compatibility (one process drives one GPU).  Without a process group (or with
+    a single rank) this is a transparent wrapper."""
 
     def __init__(self, module, device_ids=None):
         super().__init__()
         self.module = module
         self.device_ids = list(device_ids) if device_ids is not None else []
+        from .. import parallel
+        self.group = parallel.init()
+        self.grad_averagers = []
+        if self.group is not None:
+            parallel.broadcast_parameters(module, group=self.group)
+            self._wrap_create_optimizers(module)
+
+    def _wrap_create_optimizers(self, module):
+        orig = getattr(module, "create_optimizers", None)
+        if orig is None:
+            return
+        import inspect
+        from .. import parallel
+        takes_group = "group" in inspect.signature(orig).parameters          # michigan_amd.model.Pix2PixModel: FlatAdam(group=...)
+        group, averagers = self.group, self.grad_averagers
+
+        def create_optimizers(*args, **kwargs):
+            if takes_group and "group" not in kwargs:
+                kwargs["group"] = group
+            made = orig(*args, **kwargs)
+            for o in (made if isinstance(made, (tuple, list)) else (made,)):
+                av = parallel.attach_optimizer(o, group)
+                if av is not None and av not in averagers:
+                    averagers.append(av)
+            return made
+        module.create_optimizers = create_optimizers
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)

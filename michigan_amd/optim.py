@@ -57,7 +57,12 @@ class FlatAdam:
         self.sink = ops.GRAD_SINK if grad_sink is None else bool(grad_sink)
         self._build_arena()
         self._work, self._stream, self._hooks = [], None, []
-        self.overlap = True
+        # overlap=True: buckets are all-reduced while backward is still running -- valid for ONE backward() per step().  Gradient
+        # accumulation (several backward() calls per step) needs overlap=False: everything is then reduced once inside step().
+        self.overlap = os.environ.get("MG_DP_OVERLAP", "1") != "0"
+        self._launched_any = False       # a bucket of this step is (or was) in flight
+        self._synced = False             # sync_grads() already summed this step's gradients over the ranks
+        self._drained_local = False      # rank-local gradients were drained into flat_grad before any reduction (overlap off)
         # ---- autograd-path buckets (all parameters when the sink is off; unused otherwise) ---------------------
         # bucket = contiguous [lo, hi) slice of the arena; params were laid out in REVERSE registration
         # order so that backward fills the arena front to back.
@@ -122,6 +127,7 @@ class FlatAdam:
         self._table_host = self._table_dev = self._block_slot_dev = None
 
     def zero_grad(self, set_to_none: bool = False):
+        self._wait_collectives()                     # of a backward whose gradients are being discarded
         self.flat_grad.zero_()
         if self.gemm is not None and any(s.written for s in self._slot_list):      # a backward without a step(): discard it
             self.gemm[:self._gemm_used].zero_()
@@ -130,8 +136,8 @@ class FlatAdam:
             if p.grad is None or p.grad.data_ptr() != self.flat_grad[a:b].data_ptr():
                 p.grad = self.flat_grad[a:b].view(p.shape)
         self._pending = [b[2] for b in self.buckets]
-        self._work = []
         self._leftover = []
+        self._launched_any = self._drained_local = self._synced = False
 
     # ---- gradient sink: GEMM-order arena ------------------------------------------------------------
     def owns(self, p) -> bool:
@@ -151,8 +157,17 @@ class FlatAdam:
             if any(k[0] == id(w0) for k in self._slots):              # same weight, another launch geometry: keep it simple
                 return None
             sl = self._new_slot(key, w0, w1, b0, b1, taps, rows, cols)
+        if self.dp and self._synced:
+            raise RuntimeError(self._LATE_BACKWARD)
+        if sl.written and self.dp and (self._launched_any or self._work):
+            # a second backward() of this step would add rank-local gradients to an arena whose buckets are already (being) summed
+            # over the ranks: the replicas would silently diverge
+            raise RuntimeError("FlatAdam (data parallel): backward() ran again before step() while gradient buckets of this step are "
+                               "already being all-reduced; for gradient accumulation set `optimizer.overlap = False` (or "
+                               "MG_DP_OVERLAP=0): everything is then reduced once inside step()")
         if sl.written and (sl.sn is not None or sn is not None) and not self._same_sn(sl.sn, sn):
             self.drain_grads()                                        # a second forward's (u, v, sigma): flush the first one's gradient
+            self._drained_local = self.dp                             # ... rank-local: sync_grads reduces flat_grad instead of the arena
         sl.sn = sn
         dw = self.gemm[sl.off:sl.off + sl.numel].view(taps, rows, cols)
         db = self.gemm[sl.boff:sl.boff + rows] if (b0 is not None) else None
@@ -199,7 +214,7 @@ class FlatAdam:
         """Called by the autograd Functions right after they enqueued the wgrad kernel(s) of `sl`."""
         first = not sl.written
         sl.written = True
-        if self.dp and self.overlap and first and not self._recording and sl.bucket >= 0:
+        if self.dp and self.overlap and first and not self._recording and not self._drained_local and sl.bucket >= 0:
             self._gpending[sl.bucket] -= 1
             if self._gpending[sl.bucket] == 0:
                 lo, hi, _ = self._gbuckets[sl.bucket]
@@ -275,13 +290,21 @@ class FlatAdam:
         self._reset_step_state()
 
     # ---- overlapped gradient averaging ----------------------------------------------
+    _LATE_BACKWARD = ("FlatAdam (data parallel): backward() after this step's gradients were already summed over the ranks "
+                      "(sync_grads / finalize_grads / step); call zero_grad() first")
+
     def _on_grad(self, p):
+        if self._synced:
+            raise RuntimeError(self._LATE_BACKWARD)
         if self.sink:
             self._leftover.append(p)                    # reduced one by one in sync_grads (a handful of small tensors)
             return
-        if not self.overlap:
+        if not self.overlap or self._drained_local:
             return
         i = self._bucket_of[id(p)]
+        if self._pending[i] <= 0:
+            raise RuntimeError("FlatAdam (data parallel): a second backward() reached a gradient bucket that is already being "
+                               "all-reduced; for gradient accumulation set `optimizer.overlap = False` (or MG_DP_OVERLAP=0)")
         self._pending[i] -= 1
         if self._pending[i] == 0:
             self._launch(i)
@@ -289,6 +312,7 @@ class FlatAdam:
     def _all_reduce(self, chunk):
         from . import parallel
         parallel.COLLECTIVES["grad_bucket"] += 1
+        self._launched_any = True
         if chunk.is_cuda and GRAD_SIDE_STREAM == 2:
             self._work.append(dist.all_reduce(chunk, group=self.group, async_op=True))     # the process group's own stream, no extra side stream
         elif chunk.is_cuda and not GRAD_SIDE_STREAM:
@@ -311,6 +335,22 @@ class FlatAdam:
         gradient, or everything when overlap is off), wait, and drain the GEMM-order arena into the gradient arena.
         The 1/world average is folded into the Adam kernel's grad_scale."""
         scatter = None
+        if self.dp and self._synced:
+            return                                   # idempotent: step() after an explicit sync_grads() / finalize_grads()
+        if self.dp and (not self.overlap or self._drained_local):
+            # not overlapped (gradient accumulation, or rank-local gradients already sit in flat_grad): drain what is local, then reduce
+            # the reference-layout arena itself -- correct for any number of backward() calls
+            if self._launched_any or self._work:
+                raise RuntimeError("FlatAdam: `overlap` was switched off after buckets of this step were launched")
+            self.drain_grads()
+            for lo, hi, _ in self.buckets:
+                self._all_reduce(self.flat_grad[lo:hi])
+            self._wait_collectives()
+            self._pending = [0] * len(self.buckets)
+            self._leftover = []
+            self._launched_any = self._drained_local = False
+            self._synced = True
+            return
         if self.dp:
             if self.sink:
                 if self.gemm is not None and any(s.written for s in self._slot_list):
@@ -345,11 +385,7 @@ class FlatAdam:
                     if left > 0 or not self.overlap:
                         self._launch(i)
                     self._pending[i] = 0
-            for w in self._work:
-                w.wait()
-            self._work = []
-            if self._stream is not None:
-                torch.cuda.current_stream().wait_stream(self._stream)
+            self._wait_collectives()
             if scatter is not None:
                 views, buf = scatter
                 pieces = list(buf.split([v.numel() for v in views]))
@@ -358,7 +394,23 @@ class FlatAdam:
                 else:
                     for v, b in zip(views, pieces):
                         v.copy_(b)
+        self._launched_any = False
         self.drain_grads()
+        self._synced = self.dp
+
+    def _wait_collectives(self):
+        for w in self._work:
+            w.wait()
+        self._work = []
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+
+    def finalize_grads(self):
+        """Public form of what step() does first: after it every p.grad holds this step's gradient (summed over the ranks when data
+        parallel -- the 1/world average is applied inside the Adam kernel).  With the gradient sink (default) the convolutions' weight and
+        bias gradients are NOT in p.grad between backward() and step(): anything that reads gradients there (clipping, logging, a custom
+        optimiser over the same parameters) must call this first."""
+        self.sync_grads()
 
     # ---- checkpointing ----------------------------------------------------------------------
     def state_dict(self):

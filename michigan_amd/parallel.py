@@ -1,6 +1,6 @@
 """Data parallelism the MI355X way: one process per GPU (torch.distributed, backend "nccl" =
 RCCL over xGMI), weights resident on every rank, gradients averaged with a few large flat
-all-reduces issued on a side HIP stream while backward is still running.
+all-reduces issued while backward is still running.
 
 Replaces nn.DataParallel + the SyncBN thread pipe of the reference (pix2pix_trainer.py:21-24,
 sync_batchnorm/replicate.py:50-67): no per-forward parameter broadcast (0.63 GB per replica per
@@ -13,32 +13,88 @@ the process group's stream (they overlap the rest of backward; no measurable fix
 The ~42 small sync-BN reductions of a step go on the compute stream instead: on the process group's
 stream each costs two cross-stream dependencies (3.2 ms per step with one rank), about the latency it
 could hide (MG_SYNCBN_ASYNC=1 / MG_DP_GRAD_SIDE=0|1 select the other forms).
+
+Two traffic classes, two communicators: one RCCL communicator serialises its collectives, so an 8 KB
+statistics all-reduce issued behind an in-flight 64 MiB gradient bucket would wait for that bucket's
+ring time (42 times per step).  `init()` therefore creates a SECOND process group over the same ranks
+for the sync-BN reductions (`ops.SYNC_BN_GROUP`); gradient buckets keep the first (`grad_group()`).
+MG_DP_ONE_GROUP=1 puts both on one communicator again (A/B on a real node).
+
+Two consumers:
+  * this repo's trainer (`model.Pix2PixTrainer`): `optim.FlatAdam(group=grad_group())` reduces its GEMM-order
+    gradient arena in place;
+  * the reference's own trainer through `dropin.install()`: `DataParallelWithCallback` (networks/sync_batchnorm.py)
+    calls `init()`, broadcasts once and attaches a `GradAverager` to whatever optimiser
+    `Pix2PixModel.create_optimizers` returns (torch.optim.Adam, pix2pix_model.py:137-145).
 """
 from __future__ import annotations
 
 import os
+from typing import List, Optional
+
 import torch
 import torch.distributed as dist
 
 from . import ops
 
-_GROUP = None
+_GROUP = None            # gradient buckets
+_BN_GROUP = None         # sync-BN statistics (a second communicator over the same ranks)
+_OWNED = []              # groups init() created (destroyed by shutdown())
+
+
+def _forced() -> bool:
+    # MG_DP_FORCE=1 (test hook): keep every collective in the step even with a single rank, so that the RCCL call
+    # pattern (bucket all-reduces from autograd hooks, sync-BN reductions inside forward / backward) can
+    # be exercised on a one-GPU box.
+    return os.environ.get("MG_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized()
 
 
 def init(group=None):
-    """Enable cross-rank batch-norm statistics and gradient reduction on `group` (default: WORLD)."""
-    global _GROUP
-    # MG_DP_FORCE=1 (test hook): keep every collective in the step even with a single rank, so that the RCCL call
-    # pattern (side-stream bucket all-reduces from autograd hooks, sync-BN reductions inside forward / backward) can
-    # be exercised on a one-GPU box.
-    forced = os.environ.get("MG_DP_FORCE") == "1" and dist.is_available() and dist.is_initialized()
-    if not forced and (not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1):
-        _GROUP = None
+    """Enable cross-rank batch-norm statistics and gradient reduction over the ranks of `group` (default: WORLD).
+    Collective over those ranks (it creates process groups).  Returns the gradient group, or None when there is
+    nothing to reduce (no process group / one rank).  Idempotent for the same `group`."""
+    global _GROUP, _BN_GROUP
+    if not _forced() and (not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1):
+        _GROUP = _BN_GROUP = None
         ops.SYNC_BN_GROUP = None
         return None
-    _GROUP = group if group is not None else dist.group.WORLD
-    ops.SYNC_BN_GROUP = None if os.environ.get("MG_DP_NO_SYNCBN") == "1" else _GROUP      # measurement switch
+    base = group if group is not None else dist.group.WORLD
+    if _GROUP is not None and getattr(init, "_base", None) is base:
+        return _GROUP
+    init._base = base
+    _GROUP = base
+    if os.environ.get("MG_DP_ONE_GROUP") == "1":
+        _BN_GROUP = base
+    else:
+        if base is dist.group.WORLD:
+            _BN_GROUP = dist.new_group()
+        else:                                             # only the members of `base` call init(): synchronise among them
+            _BN_GROUP = dist.new_group(ranks=dist.get_process_group_ranks(base), use_local_synchronization=True)
+        _OWNED.append(_BN_GROUP)
+    ops.SYNC_BN_GROUP = None if os.environ.get("MG_DP_NO_SYNCBN") == "1" else _BN_GROUP      # measurement switch
     return _GROUP
+
+
+def shutdown():
+    """Forget the groups (tests that create several process groups in one interpreter)."""
+    global _GROUP, _BN_GROUP
+    for g in _OWNED:
+        try:
+            dist.destroy_process_group(g)
+        except Exception:                                  # the default group went first: nothing left to destroy
+            pass
+    del _OWNED[:]
+    _GROUP = _BN_GROUP = None
+    init._base = None
+    ops.SYNC_BN_GROUP = None
+
+
+def grad_group():
+    return _GROUP
+
+
+def bn_group():
+    return _BN_GROUP
 
 
 def rank() -> int:
@@ -59,9 +115,168 @@ def reset_collective_counts():
 
 
 def broadcast_parameters(module, src: int = 0, group=None):
-    """Make every rank start from rank `src`'s weights and buffers (done once, not per forward)."""
+    """Make every rank start from rank `src`'s weights and buffers (done once, not per forward -- the reference
+    re-broadcasts 0.63 GB per replica in every DataParallel.forward).  Tensors are coalesced per dtype into flat
+    buffers: a handful of collectives instead of ~600."""
     g = group if group is not None else _GROUP
     if g is None:
         return
+    src_global = dist.get_global_rank(g, src) if g is not dist.group.WORLD else src
+    seen, by_kind = set(), {}
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=g)
+        if t is None or id(t) in seen or t.numel() == 0:
+            continue
+        seen.add(id(t))
+        by_kind.setdefault((t.dtype, t.device), []).append(t.data)
+    for (_, _), tensors in by_kind.items():
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        dist.broadcast(flat, src=src_global, group=g)
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view(t.shape))
+            off += n
+
+
+class GradAverager:
+    """Bucketed, overlapped gradient averaging for ANY torch optimiser (the reference's `torch.optim.Adam`,
+    models/pix2pix_model.py:144-145): what the backward of nn.DataParallel's replicate (ReduceAddCoalesced of every
+    parameter gradient onto GPU 0) + `.mean()` of the gathered losses (pix2pix_trainer.py:42-43) amount to, as
+    d(mean_r L_r)/dtheta = (1/R) sum_r dL_r/dtheta.
+
+    Parameters are laid out in REVERSE registration order over flat fp32 buckets (backward fills them front to back).
+    `optimizer.zero_grad()` arms a step: from then on a post-accumulate hook moves every gradient into its bucket
+    (`p.grad` becomes a view of it), and the bucket is all-reduced -- asynchronously on the process group's stream --
+    as soon as its last gradient arrived.  A pre-hook of `optimizer.step()` reduces what never filled up (parameters
+    that get no gradient: the reference's unused backgroud_enc.layer4, encoder.py:283-285), waits, and applies 1/world.
+    A backward that runs while the optimiser is not armed (the generator step also back-propagates into D, whose
+    gradients the trainer discards, pix2pix_trainer.py:64) costs no communication.
+
+    More than one backward per step (gradient accumulation) cannot be overlapped -- the second backward would add
+    rank-local gradients into an already reduced bucket: it raises unless `overlap=False`, where everything is reduced
+    once inside step()."""
+
+    def __init__(self, optimizer, group, bucket_bytes: int = 64 << 20, overlap: bool = True):
+        self.optimizer, self.group = optimizer, group
+        self.world = dist.get_world_size(group)
+        self.overlap = overlap and os.environ.get("MG_DP_OVERLAP", "1") != "0"
+        params = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
+        if not params:
+            raise ValueError("GradAverager: the optimiser holds no trainable parameter")
+        self.params = list(reversed(params))
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._span, self._bucket_of, self.buckets, self._members = {}, {}, [], [[]]
+        per, off, lo = max(bucket_bytes // 4, 1), 0, 0
+        for p in self.params:
+            n = p.numel()
+            self._span[id(p)] = (off, off + n)
+            self._bucket_of[id(p)] = len(self.buckets)
+            self._members[-1].append(p)
+            off += n
+            if off - lo >= per:
+                self.buckets.append((lo, off))
+                self._members.append([])
+                lo = off
+        if self._members[-1]:
+            self.buckets.append((lo, off))
+        else:
+            self._members.pop()
+        self._armed = False
+        self._work: List = []
+        self._reset()
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._zero_grad = optimizer.zero_grad
+        optimizer.zero_grad = self._zero_grad_and_arm                      # instance attribute: the class stays torch's
+        self._step_hook = optimizer.register_step_pre_hook(lambda *_: self.finish())
+        optimizer._mg_grad_averager = self
+
+    # ---- step protocol ---------------------------------------------------------------------
+    def _reset(self):
+        self._pending = [len(m) for m in self._members]
+        self._launched = [False] * len(self.buckets)
+        self._hit = set()
+
+    def _zero_grad_and_arm(self, *a, **k):
+        self._wait()                                                         # collectives of a discarded backward
+        out = self._zero_grad(*a, **k)
+        self._reset()
+        self._armed = True
+        return out
+
+    def _adopt(self, p):
+        """Move p.grad into its bucket (autograd accumulates in place into the view afterwards)."""
+        a, b = self._span[id(p)]
+        v = self.flat[a:b].view(p.shape)
+        if p.grad.data_ptr() != v.data_ptr() or p.grad.dtype != v.dtype:
+            v.copy_(p.grad)
+            p.grad = v
+
+    def _on_grad(self, p):
+        if not (self._armed and self.overlap):
+            return
+        i = self._bucket_of[id(p)]
+        if id(p) in self._hit:                                               # a second backward() of this step
+            if self._launched[i]:
+                raise RuntimeError("GradAverager: a second backward() reached a gradient bucket that is already being all-reduced; "
+                                   "gradient accumulation needs GradAverager(overlap=False) (or MG_DP_OVERLAP=0)")
+            return
+        self._hit.add(id(p))
+        with torch.no_grad():
+            self._adopt(p)
+        self._pending[i] -= 1
+        if self._pending[i] == 0:
+            self._reduce(i)
+
+    def _reduce(self, i):
+        lo, hi = self.buckets[i]
+        self._launched[i] = True
+        COLLECTIVES["grad_bucket"] += 1
+        self._work.append(dist.all_reduce(self.flat[lo:hi], group=self.group, async_op=True))
+
+    def _wait(self):
+        for w in self._work:
+            w.wait()
+        self._work = []
+
+    def finish(self):
+        """Called in front of optimizer.step(): every rank ends up with the average gradient in p.grad (parameters
+        without a gradient keep `None`, as torch.optim expects; every rank runs the same graph, so the same ones)."""
+        with torch.no_grad():
+            for i, members in enumerate(self._members):                     # same order on every rank
+                if self._launched[i]:
+                    continue
+                for p in members:
+                    if p.grad is None:
+                        a, b = self._span[id(p)]
+                        self.flat[a:b].zero_()
+                    else:
+                        self._adopt(p)
+                self._reduce(i)
+            self._wait()
+            self.flat.mul_(1.0 / self.world)
+        self._armed = False
+        self._reset()
+
+    def detach(self):
+        for h in self._hooks:
+            h.remove()
+        self._step_hook.remove()
+        self.optimizer.zero_grad = self._zero_grad
+        self.optimizer._mg_grad_averager = None
+        self._hooks = []
+
+
+def attach_optimizer(optimizer, group=None, **kw) -> Optional[GradAverager]:
+    """Average `optimizer`'s gradients over `group` (default: the gradient group of init()).  FlatAdam reduces its own
+    arena when it is built with `group=`; anything else gets a GradAverager.  No-op without a group."""
+    g = group if group is not None else _GROUP
+    if g is None or getattr(optimizer, "_mg_grad_averager", None) is not None:
+        return getattr(optimizer, "_mg_grad_averager", None)
+    from .optim import FlatAdam
+    if isinstance(optimizer, FlatAdam):
+        if optimizer.group is None:
+            raise ValueError("FlatAdam must be constructed with group= to take part in data parallelism")
+        return None
+    return GradAverager(optimizer, g, **kw)

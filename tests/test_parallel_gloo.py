@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _one_step(rank, world, port, n_total, q, bucket_bytes=1 << 18):
+def _one_step(rank, world, port, n_total, q, bucket_bytes=1 << 18, sink=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     torch.set_num_threads(2)
@@ -42,7 +42,7 @@ def _one_step(rank, world, port, n_total, q, bucket_bytes=1 << 18):
     opt = PU.small_opt(ngf=8, crop_size=128)
     G = networks.SPADEBGenerator(opt).train()
     G.load_state_dict(synth_state_dict(G.state_dict(), seed=31, gain=1.0))
-    optim = FlatAdam(G.parameters(), lr=1e-3, betas=(0.0, 0.9), bucket_bytes=bucket_bytes, group=group)
+    optim = FlatAdam(G.parameters(), lr=1e-3, betas=(0.0, 0.9), bucket_bytes=bucket_bytes, group=group, grad_sink=sink)
     full = synth_batch(n_total, 128, seed=17)
     per = n_total // world
     b = {k: v[rank * per:(rank + 1) * per] for k, v in full.items()}
@@ -54,14 +54,25 @@ def _one_step(rank, world, port, n_total, q, bucket_bytes=1 << 18):
                 noise=b["noise"], image_tag=b["image_tag"])
         ((out * gy).sum() / per).backward()
         if it == 0:
-            untouched = [i for i, (left, b) in enumerate(zip(optim._pending, optim.buckets)) if left == b[2]]   # no gradient arrived at all
+            # buckets no gradient arrived in at all.  Autograd path (sink off): hooks count `_pending` down.  Gradient sink: the GEMM-order
+            # arena only has slots for convolutions that ran, so there "untouched" = a bucket none of whose slots was written
+            if optim.sink:
+                optim._freeze_layout() if optim._layout_dirty else None
+                written = [0] * len(optim._gbuckets)
+                for sl in optim._slot_list:
+                    written[sl.bucket] += bool(sl.written)
+                untouched = [i for i, w in enumerate(written) if w == 0]
+            else:
+                untouched = [i for i, (left, b) in enumerate(zip(optim._pending, optim.buckets)) if left == b[2]]
             optim.sync_grads()                      # summed over ranks; the 1/world average is applied inside Adam
             grad0 = (optim.flat_grad / world).numpy().copy()
             out0 = out.detach().numpy().copy()
             rm0 = G.state_dict()["up_3.norm_1.param_free_norm.running_mean"].numpy().copy()
             rv0 = G.state_dict()["head_0.norm_0.param_free_norm.running_var"].numpy().copy()
+        if it == 1 and optim.dp:                     # steady state: which arena buckets were all-reduced from inside backward
+            overlapped = ([g == 0 for g in optim._gpending] if optim.sink else [g == 0 for g in optim._pending])
         optim.step()
-    res = {"grad0": grad0, "flat": optim.flat.detach().numpy().copy(), "out": out0, "rm": rm0, "rv": rv0,      # numpy: plain pickling
+    res = {"overlapped": overlapped if optim.dp else [], "ngbuckets": len(optim._gbuckets), "grad0": grad0, "flat": optim.flat.detach().numpy().copy(), "out": out0, "rm": rm0, "rv": rv0,      # numpy: plain pickling
            "untouched": untouched, "nbuckets": len(optim.buckets)}
     q.put((rank, res))
     if world > 1:
@@ -82,12 +93,16 @@ def test_two_ranks_equal_single_process_on_concatenated_batch():
     for p in procs:
         p.start()
     got = dict(q.get(timeout=600) for _ in range(2))
+    got_raw = got
     arrays = lambda d: {k: torch.from_numpy(v) for k, v in d.items() if hasattr(v, "dtype")}
     single = arrays(single)
     got = {r: arrays(d) for r, d in got.items()}
     for p in procs:
         p.join()
         assert p.exitcode == 0
+    # gradient sink, second iteration (slot layout known): every bucket of the GEMM-order arena went out from inside backward
+    raw = dict(got_raw)
+    assert raw[0]["ngbuckets"] >= 2 and all(raw[0]["overlapped"]) and raw[0]["overlapped"] == raw[1]["overlapped"]
     # every rank holds the same parameters, equal to the single-process ones
     assert torch.equal(got[0]["flat"], got[1]["flat"])
     # averaged gradients (before Adam's sign-like normalisation, which is ill-conditioned where g ~ 0)
@@ -105,17 +120,18 @@ def test_two_ranks_equal_single_process_on_concatenated_batch():
 
 @pytest.mark.timeout(1200)
 def test_four_ranks_with_never_produced_gradient_buckets():
-    """world_size 4, one image per rank, 16 KiB buckets: several buckets hold only parameters that never receive a
-    gradient (the reference's unused backgroud_enc.layer4, encoder.py:283-285) -- no hook ever fires for them, so they
+    """world_size 4, one image per rank, 16 KiB buckets, gradients through autograd (grad_sink=False: the mode in which every parameter
+    sits in a hook-counted bucket -- with the sink the arena only has slots for convolutions that ran): several buckets hold only
+    parameters that never receive a gradient (the reference's unused backgroud_enc.layer4, encoder.py:283-285) -- no hook ever fires for them, so they
     must be flushed by sync_grads on every rank in the same order or the collectives would mismatch / hang."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_one_step, args=(0, 1, 0, 4, q, 1 << 14))
+    p = ctx.Process(target=_one_step, args=(0, 1, 0, 4, q, 1 << 14, False))
     p.start()
     _, single = q.get(timeout=600)
     p.join()
     port = _free_port()
-    procs = [ctx.Process(target=_one_step, args=(r, 4, port, 4, q, 1 << 14)) for r in range(4)]
+    procs = [ctx.Process(target=_one_step, args=(r, 4, port, 4, q, 1 << 14, False)) for r in range(4)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=900) for _ in range(4))
