@@ -176,13 +176,19 @@ def main():
     for _ in range(a.steps):
         step()
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0                         # this rank alone: when ITS last kernel finished (before the closing barrier)
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms = None
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        own = torch.zeros(world, device="cuda", dtype=torch.float64)
+        own[rank] = dt_own / a.steps * 1e3
+        dist.all_reduce(own)                                    # every rank's own ms/step: the spread shows a straggler / a stalled communicator
+        per_rank_ms = [round(v, 3) for v in own.tolist()]
     losses = {k: float(v.detach().float().mean()) for k, v in trainer.get_latest_losses().items()}
     step_gflop_ref = STEP_GFLOP_REFERENCE if a.mode == "train" else F_G
     step_gflop_min = STEP_GFLOP_MINIMUM if a.mode == "train" else F_G
@@ -216,7 +222,10 @@ def main():
             else:
                 roof = {"bound": "mfma", "kernel": "all mg_conv_taps launches", "achieved": all_conv["achieved"], "peak": peak,
                         "unit": "TFLOP/s", "frac": all_conv["frac"], "traffic": None, "all_conv_launches": all_conv}
-            tfile = os.path.join(ROOT, "profiles", "r02_conv_traffic.json")     # tools/pmc_step.sh (rocprofv3 --pmc passes, separate runs)
+            # like-for-like across rounds: the aggregate over ALL conv launches next to the dominant kernel's figures, by name
+            roof["dominant_kernel_frac"], roof["all_conv_frac"], roof["all_conv_achieved"] = roof["frac"], all_conv["frac"], all_conv["achieved"]
+            tfile = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r03_conv_traffic.json", "r02_conv_traffic.json")) if os.path.exists(f)), "")
+            # ^ tools/pmc_step.sh (rocprofv3 --pmc passes, separate runs)
             if a.mode == "train" and a.dtype == "bf16" and a.batch_per_gpu == 8 and a.size == 512 and os.path.exists(tfile):
                 with open(tfile) as fh:
                     tj = json.load(fh)
@@ -225,7 +234,11 @@ def main():
                     roof["traffic"] = round(dk["hbm_bytes_per_launch"] / 1e9, 3)
                     roof["traffic_unit"] = "GB of HBM per launch of the same kernel (2*FETCH_SIZE + WRITE_SIZE)"
                 all_conv["traffic_gb_per_step"] = round(tj["conv"]["hbm_bytes_per_step"] / 1e9, 2)
-                roof["traffic_source"] = "profiles/r02_conv_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit " + str(tj.get("commit"))
+                roof["traffic_source"] = ("profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s"
+                                          % (os.path.basename(tfile), tj.get("commit")))
+                from michigan_amd.build import _fingerprint
+                # the PMC passes are separate runs: say whether they were taken on THESE kernel sources (hash of csrc/ + include/ + flags)
+                roof["traffic_same_kernel_sources"] = tj.get("kernel_sources") == _fingerprint()[:16]
     if world > 1:
         dist.barrier()
 
@@ -251,6 +264,9 @@ def main():
                                       "gflop_per_image": [step_gflop_ref, step_gflop_min], "unit": "TFLOP/s per GPU"},
             "losses": losses,
         }
+        if per_rank_ms is not None:
+            out["per_rank_ms_per_step"] = per_rank_ms           # each rank's own clock up to its last kernel; `ms_per_step` is the max incl. the barrier
+            out["rank_spread_ms"] = round(max(per_rank_ms) - min(per_rank_ms), 3)
         if roof is not None and world > 1:
             out["collectives_per_step"] = collectives          # RCCL all-reduces one rank issues per G+D step, by kind
         if roof is not None:

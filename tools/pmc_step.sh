@@ -35,6 +35,10 @@ if calls:
                        "hbm_bytes_per_launch": (2 * tot["FETCH_SIZE"]["dominant"] + tot["WRITE_SIZE"]["dominant"]) * 1024 / calls,
                        "fetch_kib_raw_per_launch": tot["FETCH_SIZE"]["dominant"] / calls, "write_kib_per_launch": tot["WRITE_SIZE"]["dominant"] / calls}
 res["commit"] = "$COMMIT"
+import sys
+sys.path.insert(0, "$GRAFT_REPO_ROOT")
+from michigan_amd.build import _fingerprint
+res["kernel_sources"] = _fingerprint()[:16]          # bench.py compares it with the sources it runs on (roofline.traffic_same_kernel_sources)
 res["note"] = "bs 8, 512^2, bf16; per training step unless stated; read side = 2 x FETCH_SIZE (gfx950 correction), KiB -> bytes; run = warm-up step + timed step"
 json.dump(res, open("$OUT/conv_traffic.json", "w"), indent=1)
 print(json.dumps(res))
