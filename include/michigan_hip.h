@@ -388,6 +388,51 @@ int     mg_nearest_table(int32_t src, int32_t dst, int32_t* table);
 int     mg_orient_rgb_table(double* table);
 int64_t mg_noise_field_len(int32_t S);
 
+/* ---- per-pixel glue around the convolutions (mg_glue.hip): each entry replaces a chain of eager element-wise ops with one launch ---- */
+
+/* F.interpolate(mode='nearest') of planar fp32 maps (plane c of sample n starts at plane[c] + n * nstride[c], H x W) to `nlev`
+ * resolutions at once, written as NHWC tensors out[l] = [N, h[l], w[l], cout] in `dtype` with channels >= nplanes zeroed: the SPADE
+ * conditioning pyramid (normalization.py:109) and the hair / background mask pyramids (generator.py:186-219, encoder.py:331-341).
+ * Source index = min(floor(dst * (float)in / out), in - 1), as ATen's nearest kernel computes it. */
+typedef struct mg_pyramid_desc {
+    const float* plane[8];
+    int64_t nstride[8];
+    int32_t nplanes, N, H, W, nlev, cout, dtype, pad_;
+    int32_t h[8], w[8];
+    void* out[8];
+} mg_pyramid_desc;
+int mg_nearest_pyramid(const mg_pyramid_desc* d, void* stream);
+
+/* Mask half of PartialConv2d with a single-channel mask (partialconv2d.py:55-75): window sum S of mask_in [N,H,W] over k x k,
+ * stride s, zero padding p -> upd = clamp(S, 0, 1), scale = k*k / (S + 1e-8) * upd, both fp32 [N,h,w]. */
+int mg_pconv_mask(const float* mask_in, int32_t N, int32_t H, int32_t W, int32_t k, int32_t s, int32_t p,
+                  float* scale, float* upd, void* stream);
+
+/* y[p, c] = x[p, c] * a[p] (bias == NULL) or bias[c] * b[p] + x[p, c] * a[p] over P pixels x C channels (NHWC, C % 4 == 0): the
+ * partial convolution's input masking x * m and output renormalisation ((raw - b) * ratio + b) * m' = raw * (ratio m') + b * m'.
+ * bf16: a, b and bias are rounded to bf16 and bias * b is rounded once before the fused multiply-add, like the eager bf16 ops. */
+int mg_pixel_affine(const void* x, const float* a, const float* bias, const float* b, int32_t dtype, int64_t P, int32_t C,
+                    void* y, void* stream);
+
+/* Input of the background encoder (encoder.py:288-320): mode 0: back = 1 - maxpool_kxk(hair) (k odd, stride 1, padding k/2);
+ * mode 1: back = hair as given.  inp[n, y, x, 0:3] = image * back + noise * (1 - back) (noise == NULL: image * back; image == NULL:
+ * noise), channels 3..7 zero, NHWC8 in `dtype`; image / noise are NCHW fp32 with 3 channels, hair is plane [H, W] of sample n at
+ * hair + n * hair_nstride.  back: fp32 [N, H, W]. */
+int mg_bg_compose(const float* image, const float* noise, const float* hair, int64_t hair_nstride, int32_t dtype,
+                  int32_t N, int32_t H, int32_t W, int32_t k, int32_t mode, void* inp, float* back, void* stream);
+
+/* Tail of the Gabor orientation loss behind mg_gabor_argmax_fwd (loss.py:352-385).  conf_raw fp32 [N,HW] (max clamped response),
+ * idx u8 [N,HW] (winning filter), label: label_ch == 2: planes (sin 2t, cos 2t) of sample n at label + n * label_nstride (+ HW for
+ * the second); label_ch == 1: the loader's 0..255 angle map.  confidence = (tanh(conf_raw) + 1) / 2, fake = (sin 2a, cos 2a) *
+ * confidence with a = idx * pi / 32.  out[0] = mean |fake * hair - label * hair| over N*2*HW, out[1] = -sum(log(clamp(confidence,
+ * 1e-3, 1)) * hair) / sum(hair), out[2] = sum(hair); ws: >= 3072 floats.  bwd: dconf = d(g_orient[0] out[0] + g_conf[0] out[1]) / d conf_raw
+ * (either gradient pointer may be NULL = 0); fwd_out = the forward's out. */
+int mg_orient_loss_fwd(const float* conf_raw, const uint8_t* idx, const float* label, int32_t label_ch, int64_t label_nstride,
+                       const float* hair, int64_t hair_nstride, int32_t N, int64_t HW, float* out, float* ws, void* stream);
+int mg_orient_loss_bwd(const float* conf_raw, const uint8_t* idx, const float* label, int32_t label_ch, int64_t label_nstride,
+                       const float* hair, int64_t hair_nstride, const float* g_orient, const float* g_conf, const float* fwd_out,
+                       int32_t N, int64_t HW, float* dconf, void* stream);
+
 /* Hardware probes used by the test-suite (MFMA / ds_read_tr fragment maps). */
 int mg_probe_mfma_layout(float* out /* [3][64][16] */, void* stream);
 int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* out /* [64][4] */, void* stream);

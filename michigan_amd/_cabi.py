@@ -70,6 +70,13 @@ class PackJob(ctypes.Structure):
                 ("mode", _i32), ("pad_", _i32), ("first_block", _i64)]
 
 
+class PyramidDesc(ctypes.Structure):
+    """struct mg_pyramid_desc (include/michigan_hip.h)."""
+    _fields_ = [("plane", _vp * 8), ("nstride", _i64 * 8),
+                ("nplanes", _i32), ("N", _i32), ("H", _i32), ("W", _i32), ("nlev", _i32), ("cout", _i32), ("dtype", _i32), ("pad_", _i32),
+                ("h", _i32 * 8), ("w", _i32 * 8), ("out", _vp * 8)]
+
+
 class SnLayer(ctypes.Structure):
     """struct mg_sn_layer (include/michigan_hip.h)."""
     _fields_ = [("w", _vp), ("u", _vp), ("v", _vp), ("u_copy", _vp), ("v_copy", _vp), ("sigma", _vp),
@@ -116,6 +123,12 @@ _PROTOS = {
     "mg_wide_edge_weight": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp], _i32),
     "mg_hinge_fwd": ([_vp, _vp, _i32, _i64, _i32, _vp, _vp], _i32),
     "mg_hinge_bwd": ([_vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp], _i32),
+    "mg_nearest_pyramid": ([ctypes.POINTER(PyramidDesc), _vp], _i32),
+    "mg_pconv_mask": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp], _i32),
+    "mg_pixel_affine": ([_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp], _i32),
+    "mg_bg_compose": ([_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp], _i32),
+    "mg_orient_loss_fwd": ([_vp, _vp, _vp, _i32, _i64, _vp, _i64, _i32, _i64, _vp, _vp, _vp], _i32),
+    "mg_orient_loss_bwd": ([_vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
     "mg_gabor_argmax_fwd": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_gabor_argmax_bwd": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_sn_normalize": ([_vp, _i32, _f32, _vp, _vp, _vp, _vp], _i32),
@@ -174,7 +187,8 @@ class HipBackend:
             raise RuntimeError("libmichigan_hip.so ABI version mismatch")
         if (self._lib.mg_sizeof_desc(0) != ctypes.sizeof(ConvDesc) or self._lib.mg_sizeof_desc(1) != ctypes.sizeof(WgradDesc)
                 or self._lib.mg_sizeof_desc(2) != ctypes.sizeof(GradSlot) or self._lib.mg_sizeof_desc(3) != ctypes.sizeof(PackJob)
-                or self._lib.mg_sizeof_desc(4) != ctypes.sizeof(SnLayer) or self._lib.mg_sizeof_desc(5) != ctypes.sizeof(NormApply2Desc)):
+                or self._lib.mg_sizeof_desc(4) != ctypes.sizeof(SnLayer) or self._lib.mg_sizeof_desc(5) != ctypes.sizeof(NormApply2Desc)
+                or self._lib.mg_sizeof_desc(6) != ctypes.sizeof(PyramidDesc)):
             raise RuntimeError("ctypes mirror of the descriptor structs is out of sync with include/michigan_hip.h")
 
     def __getattr__(self, fn):
@@ -183,7 +197,7 @@ class HipBackend:
         raw = getattr(self._lib, fn)
         if fn in _NO_STATUS:
             return raw
-        by_ref = fn in ("mg_conv_taps", "mg_conv_wgrad", "mg_norm_bwd_apply2")
+        by_ref = fn in ("mg_conv_taps", "mg_conv_wgrad", "mg_norm_bwd_apply2", "mg_nearest_pyramid")
 
         def call(*args):
             if by_ref:

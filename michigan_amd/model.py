@@ -29,6 +29,19 @@ from .optim import FlatAdam
 SPLIT_D_IN_G_STEP = os.environ.get("MG_STACKED_D", "0") != "1"
 
 
+def _scaled(v, s):
+    return v if float(s) == 1.0 else v * s                     # x * 1.0 is exact: not worth a launch
+
+
+def _total(losses):
+    """sum(losses.values()).mean() of the reference trainer (pix2pix_trainer.py:42,67) in three launches whatever the number of terms."""
+    vals = list(losses.values())
+    if all(torch.is_tensor(v) and v.numel() == 1 for v in vals):
+        from . import ops
+        return ops.weighted_sum(vals)
+    return sum(vals).mean()
+
+
 def default_options(**over) -> argparse.Namespace:
     """Option namespace = options/base_options.py + train_options.py defaults + the README training flags."""
     d = dict(
@@ -228,10 +241,10 @@ class Pix2PixModel(nn.Module):
             if not self.opt.no_ganFeat_loss:
                 losses["GAN_Feat"] = self.criterionGANFeat(pred_fake, pred_real, label)
             if not self.opt.no_vgg_loss:
-                losses["VGG"] = self.criterionVGG(fake, d["image_tag"], label) * self.opt.lambda_vgg
+                losses["VGG"] = _scaled(self.criterionVGG(fake, d["image_tag"], label), self.opt.lambda_vgg)
         if not getattr(self.opt, "no_orient_loss", True):
             orient, conf = self.criterionOrient(fake, d["orient"], d["input_tag"])
-            losses["ORIENT"] = orient * self.opt.lambda_orient
+            losses["ORIENT"] = _scaled(orient, self.opt.lambda_orient)
             if not self.opt.no_confidence_loss:
                 losses["CONFIDENCE"] = conf * self.opt.lambda_confidence
         return losses, fake
@@ -334,7 +347,7 @@ class Pix2PixTrainer:
         self._set_d_requires_grad(False)
         try:
             g_losses, generated = self.pix2pix_model(data, mode="generator")
-            g_loss = sum(g_losses.values()).mean()
+            g_loss = _total(g_losses)
             g_loss.backward()
         finally:
             self._set_d_requires_grad(True)
@@ -344,7 +357,7 @@ class Pix2PixTrainer:
     def run_discriminator_one_step(self, data):
         self.optimizer_D.zero_grad()
         d_losses = self.pix2pix_model(data, mode="discriminator")
-        d_loss = sum(d_losses.values()).mean()
+        d_loss = _total(d_losses)
         d_loss.backward()
         self.optimizer_D.step()
         self.d_losses = d_losses

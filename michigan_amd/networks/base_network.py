@@ -16,7 +16,7 @@ class BaseNetwork(nn.Module):
         return parser
 
     # per-process caches living in the instance __dict__ (ctypes tables, weak references): never pickled / deep-copied
-    _TRANSIENT = ("_mg_input_cache", "_mg_spectral_plan")
+    _TRANSIENT = ("_mg_input_cache", "_mg_spectral_plan", "_mg_mask_chain")
 
     def __getstate__(self):
         state = dict(self.__dict__)

@@ -26,22 +26,16 @@ class PartialConv2d(HipConv2d):
         kwargs.pop("return_mask", None)
         super().__init__(*args, **kwargs)
 
-    def forward(self, x, mask_in):                      # x NHWC, mask_in [N,H,W,1] float32
-        k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
-        with torch.no_grad():
-            m = mask_in.permute(0, 3, 1, 2)
-            upd = F.avg_pool2d(m, k, s, p, count_include_pad=True) * float(k * k)     # window sum
-            ratio = (k * k) / (upd + 1e-8)
-            upd = upd.clamp(0, 1)
-            ratio = (ratio * upd).permute(0, 2, 3, 1)
-            upd = upd.permute(0, 2, 3, 1).contiguous()
-        raw = ops.conv2d(x * mask_in.to(x.dtype), self.weight, None, stride=s, padding=p)
-        # (raw * ratio + b) * m'  ==  raw * (ratio * m') + b * m'   (ratio already carries m'): two broadcast
-        # passes in the activation dtype instead of four fp32 ones
-        scale = ratio.to(x.dtype)
-        if self.bias is None:
-            return raw * scale, upd
-        return torch.addcmul(self.bias.to(x.dtype) * upd.to(x.dtype), raw, scale), upd
+    def mask_update(self, mask_in):
+        """(mask_ratio * update_mask, update_mask) for `mask_in` [N, H, W, 1] fp32 -- input-only: callers may cache it."""
+        return ops.pconv_mask(mask_in, self.kernel_size[0], self.stride[0], self.padding[0])
+
+    def forward(self, x, mask_in, precomputed=None):    # x NHWC, mask_in [N,H,W,1] float32
+        s, p = self.stride[0], self.padding[0]
+        scale, upd = precomputed if precomputed is not None else self.mask_update(mask_in)
+        raw = ops.conv2d(ops.pixel_affine(x, mask_in), self.weight, None, stride=s, padding=p)
+        # (raw * ratio + b) * m'  ==  raw * (ratio * m') + b * m'   (ratio already carries m'): one fused pass
+        return ops.pixel_affine(raw, scale, self.bias, upd if self.bias is not None else None), upd
 
 
 class ImageEncoder3(BaseNetwork):
@@ -58,11 +52,32 @@ class ImageEncoder3(BaseNetwork):
             setattr(self, "norm%d" % i, HipInstanceNorm2d(chans[i]))
         self.actvn = nn.LeakyReLU(0.2, False)
 
+    def _mask_chain(self, mask, src):
+        """The five layers' (scale, update) masks depend on the reference label only: built once per batch (5 launches) and re-used by
+        the step's second generator pass when it is handed the very same tensor, unmodified (identity + version counter)."""
+        import weakref
+        cacheable = not src.is_inference()
+        owner = src._base if src._base is not None else src          # `input[:, 1:2]` is a fresh view object per call: identify its storage owner
+        key = (src._version, src.data_ptr(), tuple(src.shape), tuple(src.stride())) if cacheable else None
+        hit = self.__dict__.get("_mg_mask_chain")
+        if cacheable and hit is not None and hit[0]() is owner and hit[1] == key:
+            return hit[2]
+        chain, m = [], mask
+        for i in range(1, 6):
+            sc, m = getattr(self, "layer%d" % i).mask_update(m)
+            chain.append((sc, m))
+        if cacheable:
+            self.__dict__["_mg_mask_chain"] = (weakref.ref(owner), key, chain)
+        return chain
+
     def forward(self, x, label_ref0, label_tag0):       # x NHWC; labels NCHW [N,1,H,W] float
         use_norm = "instance" in self.opt.norm_ref_encode
-        mask = label_ref0.permute(0, 2, 3, 1).float().contiguous()
+        mask = label_ref0.detach().permute(0, 2, 3, 1)
+        if mask.dtype != torch.float32 or not mask.is_contiguous():
+            mask = mask.float().contiguous()
+        chain = self._mask_chain(mask, label_ref0)
         for i in range(1, 6):
-            x, mask = getattr(self, "layer%d" % i)(x, mask)
+            x, mask = getattr(self, "layer%d" % i)(x, mask, precomputed=chain[i - 1])
             if use_norm:
                 x = getattr(self, "norm%d" % i)(x, act=ops.ACT_LRELU)     # norm_i then the next actvn, fused
             else:
@@ -123,26 +138,43 @@ class BackgroundEncode2(BaseNetwork):
 
     def forward(self, image, mask, noise):              # all NCHW float (3 / 2 / 3 channels)
         k = self.dilation_kernel(mask.shape[2])
-        if k is None:
-            back = mask[:, 0:1]
-        elif self.opt.add_feat_zeros and not self.opt.isTrain:
-            th, hh = self.opt.add_th, self.opt.crop_size
-            o = int(th / 2)
-            hair = mask[:, 1:2]
-            grown = hair * 0
-            grown[:, :, o:o + hh, o:o + hh] = F.max_pool2d(hair[:, :, o:o + hh, o:o + hh], k, 1, int(k / 2))
-            back = 1 - grown
+        dt = self.compute_dtype
+        fused = (mask.dtype == torch.float32 and image.shape[1] == 3 and noise.shape[1] == 3
+                 and not (self.opt.add_feat_zeros and not self.opt.isTrain) and (k is None or (k % 2 == 1 and k // 2 <= 16)))
+        if fused:
+            # dilation (k x k max-pool of the hair mask), 1 - x, image * back + noise * (1 - back), NHWC8 in the activation dtype: ONE launch
+            m = mask.detach()
+            img = None if self.opt.random_noise_background else image
+            if k is None:
+                x_in, back = ops.bg_compose(img, noise, m[:, 0], 1, 1, dt)
+            else:
+                x_in, back = ops.bg_compose(img, noise, m[:, 1], k, 0, dt)
         else:
-            # a k x k max-pool of a single-channel mask is separable: k+k taps instead of k*k (k ~ 25)
-            hair = mask[:, 1:2]
-            grown = F.max_pool2d(F.max_pool2d(hair, (k, 1), 1, (int(k / 2), 0)), (1, k), 1, (0, int(k / 2)))
-            back = 1 - grown
-        inp = noise if self.opt.random_noise_background else image * back + noise * (1 - back)
+            if k is None:
+                back = mask[:, 0:1]
+            elif self.opt.add_feat_zeros and not self.opt.isTrain:
+                th, hh = self.opt.add_th, self.opt.crop_size
+                o = int(th / 2)
+                hair = mask[:, 1:2]
+                grown = hair * 0
+                grown[:, :, o:o + hh, o:o + hh] = F.max_pool2d(hair[:, :, o:o + hh, o:o + hh], k, 1, int(k / 2))
+                back = 1 - grown
+            else:
+                # a k x k max-pool of a single-channel mask is separable: k+k taps instead of k*k (k ~ 25)
+                hair = mask[:, 1:2]
+                grown = F.max_pool2d(F.max_pool2d(hair, (k, 1), 1, (int(k / 2), 0)), (1, k), 1, (0, int(k / 2)))
+                back = 1 - grown
+            inp = noise if self.opt.random_noise_background else image * back + noise * (1 - back)
+            x_in = ops.pad_channels(ops.to_nhwc(inp, dt), 8)
         # every feature map feeds the next layer AND the generator's blend (ConvBlock ends in a ReLU): two-consumer taps
-        x0, f0 = ops.act_tap(self.conv1(ops.pad_channels(ops.to_nhwc(inp, self.compute_dtype), 8)))
+        x0, f0 = ops.act_tap(self.conv1(x_in))
         x1, f1 = ops.act_tap(self.layer1(x0))
         x2, f2 = ops.act_tap(self.layer2(x1))
         x3 = f3 = self.layer3(x2)
         sh, sw = back.shape[2], back.shape[3]
-        masks = [F.interpolate(back, size=(int(sh / d), int(sw / d)), mode="nearest") for d in (8, 4, 2)] + [back]
+        if back.dtype == torch.float32 and back.is_contiguous():
+            masks = ops.nearest_pyramid([back.detach()[:, 0]], [(int(sh / d), int(sw / d)) for d in (8, 4, 2)], 1, torch.float32)
+            masks = [m.reshape(m.shape[0], 1, m.shape[1], m.shape[2]) for m in masks] + [back]
+        else:
+            masks = [F.interpolate(back, size=(int(sh / d), int(sw / d)), mode="nearest") for d in (8, 4, 2)] + [back]
         return [f3, f2, f1, f0], masks

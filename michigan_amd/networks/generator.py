@@ -91,9 +91,15 @@ class SPADEBGenerator(BaseNetwork):
                 if opt.orient_random_disturb:
                     raise NotImplementedError("--orient_random_disturb is outside the BASELINE configs")
                 seg = torch.cat([seg, orient.float()], dim=1)
-            pyramid = SegPyramid(seg, dt)
             hh, hw = hair.shape[2], hair.shape[3]
-            hair_masks = [F.interpolate(hair, size=(int(hh / d), int(hw / d)), mode="nearest") for d in (8, 4, 2)] + [hair]
+            nup = {"normal": 5, "more": 6, "most": 7}[opt.num_upsampling_layers]
+            pyramid = SegPyramid(seg, dt, sizes=[(self.sh << i, self.sw << i) for i in range(nup + 1)])     # the SPADE layers' resolutions
+            if hair.dtype == torch.float32:
+                hp = hair.detach()[:, 0]
+                hair_masks = ops.nearest_pyramid([hp], [(int(hh / d), int(hw / d)) for d in (8, 4, 2)], 1, torch.float32)
+                hair_masks = [m.reshape(m.shape[0], 1, m.shape[1], m.shape[2]) for m in hair_masks] + [hair]
+            else:
+                hair_masks = [F.interpolate(hair, size=(int(hh / d), int(hw / d)), mode="nearest") for d in (8, 4, 2)] + [hair]
             if cacheable:
                 self.__dict__["_mg_input_cache"] = (key, tuple(weakref.ref(t) for t in src if t is not None), pyramid, hair_masks)
 

@@ -39,7 +39,23 @@ class GANLoss(nn.Module):
 
     def weight_mask(self, input, label):
         """get_weight_mask (loss.py:82-89) for one logit resolution as ONE HIP launch (index work on a 67x67 / 35x35 map)."""
-        return ops.wide_edge_weight(label, input.shape[2], input.shape[3], self.opt.wide_edge)
+        # the mask depends on the label and the logit resolution only: D's fake and real terms of one step share it
+        src = self.__dict__.get("_mg_label_src")
+        if src is None or src.data_ptr() != label.data_ptr():
+            src = label
+        owner = src._base if src._base is not None else src
+        key = (id(owner), label.data_ptr(), label._version if not label.is_inference() else -1, tuple(label.shape), tuple(label.stride()),
+               input.shape[2], input.shape[3], float(self.opt.wide_edge))
+        cache = self.__dict__.setdefault("_mg_wide_edge", {})
+        hit = cache.get(key)
+        if hit is not None and hit[0]() is owner:
+            return hit[1]
+        wm = ops.wide_edge_weight(label, input.shape[2], input.shape[3], self.opt.wide_edge)
+        if len(cache) >= 8:
+            cache.clear()
+        import weakref
+        cache[key] = (weakref.ref(owner), wm)
+        return wm
 
     def loss(self, input, target_is_real, for_discriminator=True, label=None):
         if self.gan_mode == "original":
@@ -78,13 +94,18 @@ class GANLoss(nn.Module):
         return -margin.mean()
 
     def __call__(self, input, target_is_real, for_discriminator=True, label=None):
+        self.__dict__["_mg_label_src"] = label                     # identity of the caller's tensor (detach() below makes a new object per call)
         label = label.detach().float() if label is not None else None
         if not isinstance(input, list):
             return self.loss(input, target_is_real, for_discriminator, label)
-        total = 0
+        vals = []
         for pred in input:
             pred = pred[-1] if isinstance(pred, list) else pred
-            val = self.loss(pred, target_is_real, for_discriminator, label)
+            vals.append(self.loss(pred, target_is_real, for_discriminator, label))
+        if all(v.numel() == 1 for v in vals):                      # every mode here reduces to a scalar per scale: mean over the scales
+            return ops.weighted_sum(vals, [1.0 / len(vals)] * len(vals)).reshape(1)     # [1], like the reference's view(bs, -1).mean(dim=1)
+        total = 0
+        for val in vals:
             bs = 1 if val.dim() == 0 else val.size(0)
             total = total + val.view(bs, -1).mean(dim=1)
         return total / len(input)
@@ -103,7 +124,7 @@ class GANFeatLoss(nn.Module):
 
     def forward(self, pred_fake, pred_real, label=None):
         num_d = len(pred_fake)
-        total = pred_fake[0][0].new_zeros(1, dtype=torch.float32)
+        vals = []
         for i in range(num_d):
             for j in range(len(pred_fake[i]) - 1):
                 a, b = pred_fake[i][j], pred_real[i][j].detach()
@@ -116,8 +137,10 @@ class GANFeatLoss(nn.Module):
                     val = ops.l1_mean_halves(stacked)             # fake and real are the two halves of one feature map
                 else:
                     val = ops.l1_mean(a, b)
-                total = total + val * self.opt.lambda_feat / num_d
-        return total
+                vals.append(val)
+        if not vals:
+            return pred_fake[0][0].new_zeros(1, dtype=torch.float32)
+        return ops.weighted_sum(vals, [self.opt.lambda_feat / num_d] * len(vals)).reshape(1)
 
 
 class VGGLoss(nn.Module):
@@ -139,13 +162,13 @@ class VGGLoss(nn.Module):
         with torch.no_grad():
             y_feats = self.vgg(y)
         x_feats = self.vgg(x)
-        loss = 0
-        for w, a, b in zip(self.weights, x_feats, y_feats):
+        vals = []
+        for a, b in zip(x_feats, y_feats):
             if getattr(self.opt, "remove_background", False):
-                loss = loss + w * self.L1_loss_mask(a.float(), b.detach().float(), label.detach().float())
+                vals.append(self.L1_loss_mask(a.float(), b.detach().float(), label.detach().float()))
             else:
-                loss = loss + w * ops.l1_mean(a, b)
-        return loss
+                vals.append(ops.l1_mean(a, b))
+        return ops.weighted_sum(vals, self.weights[:len(vals)])
 
 
 class L1OLoss(nn.Module):
@@ -163,10 +186,15 @@ class L1OLoss(nn.Module):
         self.register_buffer("bank", ops.gabor_bank(), persistent=False)
 
     def forward(self, fake_image0, orientation_label0, input_semantics):
-        hair = input_semantics[:, 1:2].float()
         img = fake_image0.permute(0, 2, 3, 1)                       # zero-copy for the generator's NHWC output
         conf_raw, idx = ops.gabor_argmax(img, self.bank.to(img.device))
+        # everything behind the arg-max -- tanh confidence, (sin 2a, cos 2a) of the winning filter, the masked L1 against the label,
+        # the confidence term -- is one fused reduction (mg_orient_loss_*): ~45 launches of single-channel maps per step before
+        if (not self.opt.use_ig) == (orientation_label0.shape[1] == 1) and orientation_label0.shape[1] in (1, 2):
+            orient_loss, confidence_loss = ops.orient_loss(conf_raw, idx, orientation_label0, input_semantics.detach()[:, 1])
+            return orient_loss, confidence_loss
         confidence = ((torch.tanh(conf_raw) + 1) / 2.0).unsqueeze(1)
+        hair = input_semantics[:, 1:2].float()
         ang = (idx.float() * (math.pi / self.numKernels)).unsqueeze(1)
         orient_fake = torch.cat([torch.sin(2 * ang), torch.cos(2 * ang)], dim=1) * confidence
         if not self.opt.use_ig:

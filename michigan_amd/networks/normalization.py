@@ -20,8 +20,13 @@ class SegPyramid:
     layers of the generator need only 7 distinct sizes, so the resized NHWC/compute-dtype copies are
     cached here (nearest source index = floor(dst * in / out), as F.interpolate does)."""
 
-    def __init__(self, seg_nchw: torch.Tensor, dtype):
+    def __init__(self, seg_nchw: torch.Tensor, dtype, sizes=None):
         self.seg, self.dtype, self._cache = seg_nchw, dtype, {}
+        if sizes and seg_nchw.shape[1] <= 8 and len(sizes) <= 8:
+            # every resolution the network will ask for, as NHWC8 in the activation dtype: one launch (mg_nearest_pyramid)
+            sizes = [(int(h), int(w)) for h, w in sizes]
+            for key, t in zip(sizes, ops.nearest_pyramid(ops.planes_of(seg_nchw), sizes, 8, dtype)):
+                self._cache[key] = t
 
     def at(self, h: int, w: int) -> torch.Tensor:
         key = (h, w)

@@ -1232,6 +1232,194 @@ def l1_mean(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return _L1MeanFn.apply(a, b)
 
 
+# ----------------------------------------------------------------------------
+# per-pixel glue around the convolutions (mg_glue.hip): one launch each instead of chains of eager element-wise ops
+# ----------------------------------------------------------------------------
+def _plane_args(t: torch.Tensor):
+    """(pointer, sample stride in elements) of an fp32 [N, H, W] view whose rows are dense (a channel slice of an NCHW tensor)."""
+    if t.dtype != torch.float32 or t.dim() != 3 or t.stride(2) != 1 or t.stride(1) != t.shape[2]:
+        raise ValueError("expected an fp32 [N, H, W] view with dense rows")
+    return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else t.shape[1] * t.shape[2])
+
+
+def planes_of(t: torch.Tensor):
+    """The channel planes of an NCHW fp32 tensor as [N, H, W] views (no copy when the tensor is dense)."""
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return [t[:, c] for c in range(t.shape[1])]
+
+
+def nearest_pyramid(planes, sizes, cout: int, dtype):
+    """F.interpolate(cat(planes), size, mode='nearest') for every (h, w) of `sizes`, each as an NHWC [N, h, w, cout] tensor in
+    `dtype` (channels beyond len(planes) zero): ONE launch for the whole pyramid.  planes: fp32 [N, H, W] views."""
+    n, H, W = planes[0].shape
+    if not (1 <= len(planes) <= 8 and len(planes) <= cout <= 8 and 1 <= len(sizes) <= 8):
+        raise ValueError("nearest_pyramid: at most 8 planes / channels / levels")
+    d = C.PyramidDesc()
+    for c, pl in enumerate(planes):
+        if pl.shape != planes[0].shape or pl.device != planes[0].device:
+            raise ValueError("nearest_pyramid: planes disagree in shape / device")
+        d.plane[c], d.nstride[c] = _plane_args(pl)
+    d.nplanes, d.N, d.H, d.W, d.nlev, d.cout = len(planes), n, H, W, len(sizes), cout
+    outs = []
+    d.dtype = C.MG_BF16 if dtype == torch.bfloat16 else C.MG_F32
+    for l, (h, w) in enumerate(sizes):
+        o = torch.empty((n, int(h), int(w), cout), dtype=dtype, device=planes[0].device)
+        d.h[l], d.w[l], d.out[l] = int(h), int(w), o.data_ptr()
+        outs.append(o)
+    C.backend().mg_nearest_pyramid(d, _stream(planes[0]))
+    return outs
+
+
+def pconv_mask(mask: torch.Tensor, k: int, s: int, p: int):
+    """Mask half of a partial convolution: mask fp32 [N, H, W(, 1)] -> (mask_ratio * update_mask, update_mask), fp32 [N, h, w, 1]."""
+    m = mask.detach()
+    if m.dim() == 4:
+        m = m.reshape(m.shape[0], m.shape[1], m.shape[2]) if m.shape[3] == 1 else m[:, 0]
+    m = m.float().contiguous()
+    n, H, W = m.shape
+    h, w = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    scale = torch.empty((n, h, w, 1), dtype=torch.float32, device=m.device)
+    upd = torch.empty((n, h, w, 1), dtype=torch.float32, device=m.device)
+    C.backend().mg_pconv_mask(_p(m), n, H, W, k, s, p, _p(scale), _p(upd), _stream(m))
+    return scale, upd
+
+
+class _PixelAffineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, a, bias, b):
+        x = _nhwc(x)
+        c = x.shape[-1]
+        pix = x.numel() // c
+        if a.numel() != pix or a.dtype != torch.float32 or (b is not None and (b.numel() != pix or b.dtype != torch.float32)):
+            raise ValueError("pixel_affine: one fp32 value per pixel expected")
+        y = torch.empty_like(x)
+        bf = bias.detach().float().contiguous() if bias is not None else None
+        C.backend().mg_pixel_affine(_p(x), _p(a), _p(bf), _p(b) if bias is not None else None, _dt(x), pix, c, _p(y), _stream(x))
+        ctx.save_for_backward(a, b if bias is not None else None)
+        ctx.bias_dtype = bias.dtype if bias is not None else None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        c = g.shape[-1]
+        dx = dbias = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(g)
+            C.backend().mg_pixel_affine(_p(g), _p(a), None, None, _dt(g), g.numel() // c, c, _p(dx), _stream(g))
+        if ctx.needs_input_grad[2]:
+            dbias = torch.mv(g.reshape(-1, c).float().t(), b.reshape(-1)).to(ctx.bias_dtype)       # sum_p g[p, c] * b[p]
+        return dx, None, dbias, None
+
+
+def pixel_affine(x: torch.Tensor, a: torch.Tensor, bias: Optional[torch.Tensor] = None, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y[p, c] = x[p, c] * a[p] (+ bias[c] * b[p]) on an NHWC tensor; a, b: fp32, one value per pixel.  Differentiable w.r.t. x and bias."""
+    if x.shape[-1] % 4:
+        y = x * a.reshape(x.shape[:-1] + (1,)).to(x.dtype)
+        return y if bias is None else y + bias.to(x.dtype) * b.reshape(x.shape[:-1] + (1,)).to(x.dtype)
+    return _PixelAffineFn.apply(x, a.contiguous(), bias, b.contiguous() if b is not None else None)
+
+
+def bg_compose(image: Optional[torch.Tensor], noise: Optional[torch.Tensor], hair: torch.Tensor, k: int, mode: int, dtype):
+    """Background-encoder input in one launch: (inp NHWC8 in `dtype`, back fp32 [N, 1, H, W]).  image / noise: NCHW fp32 (3 channels),
+    hair: fp32 [N, H, W] view; mode 0: back = 1 - maxpool_kxk(hair), mode 1: back = hair."""
+    src = image if image is not None else noise
+    n, _, H, W = src.shape
+    img = image.detach().float().contiguous() if image is not None else None
+    noi = noise.detach().float().contiguous() if noise is not None else None
+    hp, hs = _plane_args(hair.detach())
+    inp = torch.empty((n, H, W, 8), dtype=dtype, device=src.device)
+    back = torch.empty((n, 1, H, W), dtype=torch.float32, device=src.device)
+    C.backend().mg_bg_compose(_p(img), _p(noi), hp, hs, C.MG_BF16 if dtype == torch.bfloat16 else C.MG_F32, n, H, W, int(k), int(mode),
+                              _p(inp), _p(back), _stream(src))
+    return inp, back
+
+
+class _OrientLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, conf_raw, idx, label, hair):
+        n, h, w = conf_raw.shape
+        out = torch.empty(3, dtype=torch.float32, device=conf_raw.device)
+        ws = torch.empty(3 * 1024, dtype=torch.float32, device=conf_raw.device)
+        hp, hs = _plane_args(hair)
+        C.backend().mg_orient_loss_fwd(_p(conf_raw), _p(idx), _p(label), label.shape[1], label.stride(0), hp, hs, n, h * w, _p(out), _p(ws),
+                                       _stream(conf_raw))
+        ctx.save_for_backward(conf_raw, idx, label, hair, out)
+        ctx.set_materialize_grads(False)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_orient, g_conf):
+        conf_raw, idx, label, hair, out = ctx.saved_tensors
+        if g_orient is None and g_conf is None:
+            return None, None, None, None
+        n, h, w = conf_raw.shape
+        fix = lambda g: None if g is None else (g if g.dtype == torch.float32 else g.float())
+        g_orient, g_conf = fix(g_orient), fix(g_conf)
+        hp, hs = _plane_args(hair)
+        d = torch.empty_like(conf_raw)
+        C.backend().mg_orient_loss_bwd(_p(conf_raw), _p(idx), _p(label), label.shape[1], label.stride(0), hp, hs, _p(g_orient), _p(g_conf),
+                                       _p(out), n, h * w, _p(d), _stream(conf_raw))
+        return d, None, None, None
+
+
+def orient_loss(conf_raw: torch.Tensor, idx: torch.Tensor, label: torch.Tensor, hair: torch.Tensor):
+    """(orientation L1, confidence loss) of L1OLoss behind the Gabor arg-max (loss.py:352-385): conf_raw fp32 [N,H,W], idx u8 [N,H,W],
+    label fp32 [N, 1 or 2, H, W] (0..255 angle map or (sin 2t, cos 2t) planes), hair fp32 [N, H, W] view.  Two launches forward, one backward."""
+    label = label.detach().float()
+    if not label.is_contiguous():
+        label = label.contiguous()
+    hair = hair.detach()
+    if hair.dtype != torch.float32:
+        hair = hair.float()
+    return _OrientLossFn.apply(conf_raw.contiguous(), idx.contiguous(), label, hair)
+
+
+class _WeightedSumFn(torch.autograd.Function):
+    """sum_k w_k * v_k of K scalar tensors as THREE launches forward (stack, mul, sum) and ONE backward (g * w), whatever K: the loss
+    modules used to chain `total = total + val * w` -- 2 launches forward and 2 backward per term, ~100 five-microsecond
+    launches per training step for the feature-matching / VGG / multi-scale GAN sums (tools/count_launches.py)."""
+
+    @staticmethod
+    def forward(ctx, wvec, *vals):
+        stacked = torch.stack([v.reshape(()) for v in vals])
+        if stacked.dtype != torch.float32:
+            stacked = stacked.float()
+        ctx.save_for_backward(wvec)
+        ctx.dtypes = [v.dtype for v in vals]
+        ctx.shapes = [v.shape for v in vals]
+        return (stacked * wvec).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (wvec,) = ctx.saved_tensors
+        gv = g * wvec                                             # one launch; the per-term gradients are views of it
+        return (None,) + tuple(gv[k].reshape(sh) if dt == gv.dtype else gv[k].reshape(sh).to(dt) for k, (dt, sh) in enumerate(zip(ctx.dtypes, ctx.shapes)))
+
+
+_WSUM_WEIGHTS = {}
+
+
+def weighted_sum(vals, weights=None) -> torch.Tensor:
+    """sum_k weights[k] * vals[k] for scalar (0-d / 1-element) tensors; weights default to 1.  fp32 result."""
+    vals = list(vals)
+    if len(vals) == 1 and (weights is None or float(weights[0]) == 1.0):
+        return vals[0].reshape(()).float() if vals[0].dtype != torch.float32 else vals[0].reshape(())
+    w = tuple(1.0 for _ in vals) if weights is None else tuple(float(x) for x in weights)
+    key = (w, vals[0].device)
+    wvec = _WSUM_WEIGHTS.get(key)
+    if wvec is None:
+        if len(_WSUM_WEIGHTS) > 256:
+            _WSUM_WEIGHTS.clear()
+        wvec = _WSUM_WEIGHTS[key] = torch.tensor(w, dtype=torch.float32, device=vals[0].device)
+    return _WeightedSumFn.apply(wvec, *vals)
+
+
 class _HingeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, mode):

@@ -675,6 +675,107 @@ class EmulatorBackend:
         _view(table, (dst,), torch.int32)[:] = torch.from_numpy(IO.pil_nearest_table(src, dst))
         return 0
 
+    # ---- per-pixel glue (mg_glue.hip): contracts stated with torch's own ops, the ones the host stack used to call ------------
+    @staticmethod
+    def _plane(ptr, n, nstride, H, W):
+        """[N, H, W] view of planes that sit nstride floats apart (a channel slice of an NCHW tensor)."""
+        base = _view(ptr, ((n - 1) * nstride + H * W,), torch.float32)
+        return torch.as_strided(base, (n, H, W), (nstride, W, 1))
+
+    def mg_nearest_pyramid(self, d, stream=None):
+        import torch.nn.functional as F
+        td = _TD[d.dtype]
+        planes = torch.stack([self._plane(d.plane[c], d.N, d.nstride[c], d.H, d.W) for c in range(d.nplanes)], dim=1)   # [N, C, H, W]
+        for lev in range(d.nlev):
+            h, w = d.h[lev], d.w[lev]
+            r = planes if (h, w) == (d.H, d.W) else F.interpolate(planes, size=(h, w), mode="nearest")
+            o = _view(d.out[lev], (d.N, h, w, d.cout), td)
+            o.zero_()
+            o[..., :d.nplanes] = r.permute(0, 2, 3, 1).to(td)
+        return 0
+
+    def mg_pconv_mask(self, mask_in, N, H, W, k, s, p, scale, upd, stream=None):
+        import torch.nn.functional as F
+        m = _view(mask_in, (N, 1, H, W), torch.float32).double()
+        ssum = F.conv2d(m, torch.ones(1, 1, k, k, dtype=torch.float64), stride=s, padding=p)       # partialconv2d.py:62-64
+        ratio = (k * k) / (ssum + 1e-8)
+        u = ssum.clamp(0, 1)
+        h, w = ssum.shape[2], ssum.shape[3]
+        _view(scale, (N, 1, h, w), torch.float32)[:] = (ratio * u).float()
+        _view(upd, (N, 1, h, w), torch.float32)[:] = u.float()
+        return 0
+
+    def mg_pixel_affine(self, x, a, bias, b, dtype, P, C, y, stream=None):
+        td = _TD[dtype]
+        xv = _view(x, (P, C), td)
+        av = _view(a, (P, 1), torch.float32).to(td)
+        if _addr(bias):
+            t = _view(bias, (1, C), torch.float32).to(td) * _view(b, (P, 1), torch.float32).to(td)     # rounded to the activation dtype
+            out = (t.double() + xv.double() * av.double()).to(td)
+        else:
+            out = (xv.double() * av.double()).to(td)
+        _view(y, (P, C), td)[:] = out
+        return 0
+
+    def mg_bg_compose(self, image, noise, hair, hair_nstride, dtype, N, H, W, k, mode, inp, back, stream=None):
+        import torch.nn.functional as F
+        td = _TD[dtype]
+        hp = self._plane(hair, N, hair_nstride, H, W).unsqueeze(1)
+        if mode == 0:
+            bk = 1 - F.max_pool2d(hp, k, 1, k // 2)                                                  # encoder.py:288-297
+        else:
+            bk = hp.clone()
+        img = _view(image, (N, 3, H, W), torch.float32) if _addr(image) else None
+        noi = _view(noise, (N, 3, H, W), torch.float32) if _addr(noise) else None
+        if noi is None:
+            v = img * bk
+        elif img is None:
+            v = noi
+        else:
+            v = img * bk + noi * (1 - bk)
+        o = _view(inp, (N, H, W, 8), td)
+        o.zero_()
+        o[..., :3] = v.permute(0, 2, 3, 1).to(td)
+        _view(back, (N, H, W), torch.float32)[:] = bk[:, 0]
+        return 0
+
+    def _orient_terms(self, conf_raw, idx, label, label_ch, label_nstride, hair, hair_nstride, N, HW):
+        cr = _view(conf_raw, (N, HW), torch.float32).double()
+        ix = _view(idx, (N, HW), torch.uint8).double()
+        hv = self._plane(hair, N, hair_nstride, 1, HW).reshape(N, HW).double()
+        if label_ch == 2:
+            base = _view(label, ((N - 1) * label_nstride + 2 * HW,), torch.float32)
+            lab = torch.as_strided(base, (N, 2, HW), (label_nstride, HW, 1)).double()
+            l0, l1 = lab[:, 0], lab[:, 1]
+        else:
+            a = self._plane(label, N, label_nstride, 1, HW).reshape(N, HW).double() / 255 * math.pi
+            l0, l1 = torch.sin(2 * a), torch.cos(2 * a)
+        conf = (torch.tanh(cr) + 1) / 2
+        ang = ix * (math.pi / 32)
+        f0, f1 = torch.sin(2 * ang), torch.cos(2 * ang)
+        d0, d1 = f0 * conf * hv - l0 * hv, f1 * conf * hv - l1 * hv
+        return cr, hv, conf, f0, f1, d0, d1
+
+    def mg_orient_loss_fwd(self, conf_raw, idx, label, label_ch, label_nstride, hair, hair_nstride, N, HW, out, ws, stream=None):
+        cr, hv, conf, f0, f1, d0, d1 = self._orient_terms(conf_raw, idx, label, label_ch, label_nstride, hair, hair_nstride, N, HW)
+        o = _view(out, (3,), torch.float32)
+        o[0] = float((d0.abs().sum() + d1.abs().sum()) / (2 * N * HW))                              # F.l1_loss over [N, 2, H, W]
+        o[1] = float(-(torch.log(conf.clamp(0.001, 1)) * hv).sum() / hv.sum())
+        o[2] = float(hv.sum())
+        return 0
+
+    def mg_orient_loss_bwd(self, conf_raw, idx, label, label_ch, label_nstride, hair, hair_nstride, g_orient, g_conf, fwd_out, N, HW, dconf, stream=None):
+        cr, hv, conf, f0, f1, d0, d1 = self._orient_terms(conf_raw, idx, label, label_ch, label_nstride, hair, hair_nstride, N, HW)
+        g0 = float(_view(g_orient, (1,), torch.float32)[0]) if _addr(g_orient) else 0.0
+        g1 = float(_view(g_conf, (1,), torch.float32)[0]) if _addr(g_conf) else 0.0
+        sh = float(_view(fwd_out, (3,), torch.float32)[2])
+        dcf = g0 / (2 * N * HW) * (torch.sign(d0) * f0 + torch.sign(d1) * f1) * hv
+        inside = ((conf >= 0.001) & (conf <= 1)).double()
+        dcf = dcf - g1 / sh * hv / conf * inside
+        t = torch.tanh(cr)
+        _view(dconf, (N, HW), torch.float32)[:] = (dcf * (1 - t * t) * 0.5).float()
+        return 0
+
     def mg_orient_rgb_table(self, table):
         from oracle import inputs_oracle as IO
         _view(table, (256, 3), torch.float64)[:] = torch.from_numpy(IO.orient_rgb_table())

@@ -123,8 +123,11 @@ def _toy_worker(rank, world, port, q, mode):
                     res["raised"] = False
                 except RuntimeError as e:
                     res["raised"] = "second backward" in str(e)
-                q.put((rank, res))
-                return                                                         # gradients are spoiled: stop here (both ranks do)
+                q.put((rank, {"raised": res["raised"]}))                        # plain values only: tensors would travel through shared memory
+                av._wait()                                                     # gradients are spoiled: finish what is in flight and stop (both ranks do)
+                dist.barrier()
+                dist.destroy_process_group()
+                return
         if it == 0 and av is not None:
             launched_in_backward = sum(av._launched)
         opt.step()
