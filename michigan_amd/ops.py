@@ -637,9 +637,62 @@ def _count_collective(kind: str):
 _BIAS_PAIR_CACHE = {}
 
 
+_BIAS_PLANS = {}        # id(arena) -> plan of ALL (mlp_gamma.bias, mlp_beta.bias) pairs living in that optimiser arena
+
+
+class _BiasPlan:
+    """Every SPADE layer of a network needs its two bias vectors interleaved in the fused conv's GEMM row order, and they all change
+    together (one optimiser step).  Parameters of a FlatAdam arena are slices of ONE flat tensor, so all pairs are refreshed by a single
+    index_select over the arena (18 layers: 18 `stack` launches per optimiser step before)."""
+
+    def __init__(self, arena):
+        self.arena = weakref.ref(arena)
+        self.pairs, self.known = [], set()
+        self.index = self.mask = None
+        self.flat_ptr = 0
+
+    def register(self, bg, bb):
+        key = (id(bg), id(bb))
+        if key not in self.known:
+            self.known.add(key)
+            self.pairs.append((weakref.ref(bg), weakref.ref(bb)))
+            self.index = None
+
+    def refresh(self):
+        arena = self.arena()
+        live = [(r0(), r1()) for r0, r1 in self.pairs]
+        if arena is None or any(a is None or b is None for a, b in live):
+            return False
+        if self.index is None or self.flat_ptr != arena.flat.data_ptr():
+            idx, msk, self.offsets, off, padded = [], [], [], 0, False
+            for bg, bb in live:
+                c = bg.numel()
+                cr = _roundup(c, 32)
+                o0, o1 = arena._span_of[id(bg)][0], arena._span_of[id(bb)][0]
+                ch = torch.arange(cr).reshape(cr // 32, 1, 32)
+                src = torch.cat([o0 + ch, o1 + ch], dim=1)                       # [blocks][gamma | beta][32]
+                ok = (ch < c).expand(cr // 32, 2, 32)
+                padded = padded or cr != c
+                idx.append(torch.where(ok, src, torch.zeros_like(src)).reshape(-1))
+                msk.append(ok.reshape(-1))
+                self.offsets.append((off, off + 2 * cr))
+                off += 2 * cr
+            dev = arena.flat.device
+            self.index = torch.cat(idx).to(dev)
+            self.mask = torch.cat(msk).to(dev).float() if padded else None
+            self.flat_ptr = arena.flat.data_ptr()
+        rows = torch.index_select(arena.flat.detach(), 0, self.index)
+        if self.mask is not None:
+            rows = rows * self.mask
+        for (bg, bb), (a, b) in zip(live, self.offsets):
+            state = (bg._version, bb._version, _arena_epoch(bg), _arena_epoch(bb))
+            _BIAS_PAIR_CACHE[(bg.data_ptr(), bb.data_ptr())] = (state, weakref.ref(bg), weakref.ref(bb), rows[a:b])
+        return True
+
+
 def spade_bias_rows(bg: torch.Tensor, bb: torch.Tensor) -> torch.Tensor:
     """_interleave32 of the (mlp_gamma.bias, mlp_beta.bias) parameters, cached until either changes (tensor versions + the
-    optimiser arena's update count, like pack_weight): 18 SPADE layers x 2 generator forwards re-built it every time."""
+    optimiser arena's update count, like pack_weight); pairs that live in a FlatAdam arena are refreshed all at once (_BiasPlan)."""
     if not (isinstance(bg, torch.nn.Parameter) and isinstance(bb, torch.nn.Parameter)):
         return _interleave32(bg.detach().float(), bb.detach().float()).contiguous()
     key = (bg.data_ptr(), bb.data_ptr())
@@ -647,6 +700,18 @@ def spade_bias_rows(bg: torch.Tensor, bb: torch.Tensor) -> torch.Tensor:
     hit = _BIAS_PAIR_CACHE.get(key)
     if hit is not None and hit[0] == state and hit[1]() is bg and hit[2]() is bb:
         return hit[3]
+    arena = getattr(bg, "_mg_arena", None)
+    if arena is not None and getattr(bb, "_mg_arena", None) is arena and hasattr(arena, "_span_of") and BATCHED_PACK:
+        plan = _BIAS_PLANS.get(id(arena))
+        if plan is None or plan.arena() is not arena:
+            for k in [k for k, v in _BIAS_PLANS.items() if v.arena() is None]:
+                del _BIAS_PLANS[k]
+            plan = _BIAS_PLANS[id(arena)] = _BiasPlan(arena)
+        plan.register(bg, bb)
+        if len(_BIAS_PAIR_CACHE) > 1024:
+            _BIAS_PAIR_CACHE.clear()
+        if plan.refresh():
+            return _BIAS_PAIR_CACHE[key][3]
     rows = _interleave32(bg.detach().float(), bb.detach().float()).contiguous()
     if len(_BIAS_PAIR_CACHE) > 1024:
         _BIAS_PAIR_CACHE.clear()

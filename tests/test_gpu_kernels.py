@@ -867,3 +867,67 @@ def test_relu_tap_and_masked_maxpool_backward(dt):
         want = torch.autograd.grad(loss, [xt, w1, w2])
         _close("relu tap f32 dx vs torch", hip[2], want[0].permute(0, 2, 3, 1), 1e-4)
         _close("relu tap f32 dw1 vs torch", hip[3], want[1], 1e-4)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_glue_kernels_match_contract(dt):
+    """mg_glue.hip (the fused per-pixel passes around the convolutions) vs the contract emulator, whose contracts are written with the
+    torch ops the host stack used to call (F.interpolate, F.max_pool2d, F.conv2d on the mask, ...): index / mask work bit-exact,
+    value work within the dtype's rounding."""
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(77)
+    td = DT[dt]
+    # nearest pyramid: planes that are channel slices of NCHW tensors, ragged target sizes, zero-padded channels
+    seg = torch.cat([(torch.rand(3, 2, 72, 60, generator=g) > 0.5).float(), torch.randn(3, 2, 72, 60, generator=g)], dim=1)
+    sizes = [(9, 8), (18, 15), (36, 30), (72, 60), (50, 41)]
+
+    def pyr(seg):
+        outs = ops.nearest_pyramid(ops.planes_of(seg), sizes, 8, td)
+        outs += ops.nearest_pyramid([seg[:, 1]], [(int(72 / d), int(60 / d)) for d in (8, 4, 2)], 1, torch.float32)
+        return outs
+    (hip, _), (ref, _) = _both(pyr, (seg,))
+    for a, b in zip(hip, ref):
+        assert torch.equal(a.cpu().view(torch.int16 if a.dtype == torch.bfloat16 else torch.int32), b.view(torch.int16 if b.dtype == torch.bfloat16 else torch.int32))
+    # partial-conv mask chain + per-pixel affine (forward and both gradients)
+    mask = (torch.rand(2, 40, 36, 1, generator=g) > 0.6).float()
+    x = torch.randn(2, 40, 36, 16, generator=g).to(td).requires_grad_()
+    raw = torch.randn(2, 20, 18, 24, generator=g).to(td).requires_grad_()
+    bias = torch.randn(24, generator=g).requires_grad_()
+
+    def pc(mask, x, raw, bias):
+        sc, up = ops.pconv_mask(mask, 3, 2, 1)
+        y0 = ops.pixel_affine(x, mask)
+        y1 = ops.pixel_affine(raw, sc, bias, up)
+        gx, = torch.autograd.grad(y0.float().square().sum(), x)
+        graw, gb = torch.autograd.grad((y1.float() * 0.5).square().sum(), (raw, bias))
+        return sc, up, y0, y1, gx, graw, gb
+    (hip, _), (ref, _) = _both(pc, (mask, x, raw, bias))
+    assert torch.equal(hip[0].cpu(), ref[0]) and torch.equal(hip[1].cpu(), ref[1])
+    for i, name in ((2, "x*m"), (3, "raw*scale+b*m'"), (4, "d x"), (5, "d raw")):
+        _close(f"pixel_affine {dt} {name}", hip[i], ref[i], TOL[dt])
+    _close(f"pixel_affine {dt} d bias", hip[6], ref[6], 2e-2 if dt == "bf16" else 1e-4)
+    # background-encoder input: dilation windows up to 33, ragged image size, both modes
+    image, noise = torch.rand(2, 3, 70, 90, generator=g) * 2 - 1, torch.rand(2, 3, 70, 90, generator=g)
+    m2 = torch.zeros(2, 2, 70, 90)
+    m2[:, 1, 20:45, 30:70] = 1.0
+    m2[:, 0] = 1 - m2[:, 1]
+    for k, mode in ((5, 0), (25, 0), (33, 0), (1, 1)):
+        def bgc(image, noise, m2):
+            return ops.bg_compose(image, noise, m2[:, 1] if mode == 0 else m2[:, 0], k, mode, td)
+        (hip, _), (ref, _) = _both(bgc, (image, noise, m2))
+        assert torch.equal(hip[1].cpu(), ref[1]), (k, mode)
+        _close(f"bg_compose {dt} k={k}", hip[0], ref[0], TOL[dt])
+    # orientation-loss tail: both label forms, gradient of either output
+    conf_raw = (torch.randn(2, 48, 40, generator=g) * 1.5).requires_grad_()
+    idx = torch.randint(0, 32, (2, 48, 40), generator=g, dtype=torch.uint8)
+    sem = torch.zeros(2, 2, 48, 40)
+    sem[:, 1, 10:40, 8:30] = 1.0
+    for label in (torch.randn(2, 2, 48, 40, generator=g).clamp(-1, 1), torch.randint(0, 255, (2, 1, 48, 40), generator=g).float()):
+        def ol(conf_raw, idx, label, sem):
+            lo, lc = ops.orient_loss(conf_raw, idx, label, sem[:, 1])
+            g0, = torch.autograd.grad(lo * 3.0, conf_raw, retain_graph=True)
+            g1, = torch.autograd.grad(lo + lc * 0.25, conf_raw)
+            return lo.reshape(1), lc.reshape(1), g0, g1
+        (hip, _), (ref, _) = _both(ol, (conf_raw, idx, label, sem))
+        for i in range(4):
+            _close(f"orient_loss {label.shape[1]}ch out {i}", hip[i], ref[i], 2e-5)

@@ -184,3 +184,60 @@ def test_hinge_and_wide_edge_match_reference_formula(emulator_backend):
             gg, = torch.autograd.grad(got * 3.0, x)
             gw, = torch.autograd.grad(want * 3.0, x)
             assert (gg - gw).abs().max() < 1e-7
+
+
+def test_glue_contracts_match_the_eager_chains_they_replace(emulator_backend):
+    """mg_glue.hip's contracts (as the emulator states them) against the reference's own formulas written with plain torch ops:
+    partial-conv mask update (partialconv2d.py:55-75), output renormalisation, the background-encoder input (encoder.py:288-320), the
+    orientation-loss tail (loss.py:352-385) incl. its gradient, nearest pyramids (normalization.py:109)."""
+    import math
+    import torch.nn.functional as F
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(5)
+    # partial conv, single-channel mask
+    mask = (torch.rand(2, 1, 24, 20, generator=g) > 0.5).float()
+    x = torch.randn(2, 8, 24, 20, generator=g)
+    w, b = torch.randn(12, 8, 3, 3, generator=g) * 0.2, torch.randn(12, generator=g)
+    upd = F.conv2d(mask, torch.ones(1, 1, 3, 3), stride=2, padding=1)
+    ratio = 9.0 / (upd + 1e-8)
+    updc = upd.clamp(0, 1)
+    ratio = ratio * updc
+    raw = F.conv2d(x * mask, w, b, stride=2, padding=1)
+    want = ((raw - b.view(1, -1, 1, 1)) * ratio + b.view(1, -1, 1, 1)) * updc
+    sc, up = ops.pconv_mask(mask.permute(0, 2, 3, 1).contiguous(), 3, 2, 1)
+    raw_nb = F.conv2d(x * mask, w, None, stride=2, padding=1).permute(0, 2, 3, 1).contiguous()
+    got = ops.pixel_affine(raw_nb, sc, b, up).permute(0, 3, 1, 2)
+    assert torch.equal(up.permute(0, 3, 1, 2), updc) and (got - want).abs().max() < 1e-5
+    xm = ops.pixel_affine(x.permute(0, 2, 3, 1).contiguous(), mask.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(xm.permute(0, 3, 1, 2), x * mask)
+    # background-encoder input
+    image, noise = torch.rand(2, 3, 40, 44, generator=g), torch.rand(2, 3, 40, 44, generator=g)
+    m2 = torch.zeros(2, 2, 40, 44)
+    m2[:, 1, 10:25, 12:30] = 1
+    k = 7
+    back = 1 - F.max_pool2d(m2[:, 1:2], k, 1, k // 2)
+    inp = image * back + noise * (1 - back)
+    got_inp, got_back = ops.bg_compose(image, noise, m2[:, 1], k, 0, torch.float32)
+    assert torch.equal(got_back, back) and (got_inp[..., :3].permute(0, 3, 1, 2) - inp).abs().max() < 1e-6 and float(got_inp[..., 3:].abs().max()) == 0
+    # nearest pyramid == F.interpolate per level
+    seg = torch.randn(2, 4, 40, 44, generator=g)
+    for t, (h, w_) in zip(ops.nearest_pyramid(ops.planes_of(seg), [(5, 5), (10, 11), (20, 22)], 8, torch.float32), [(5, 5), (10, 11), (20, 22)]):
+        assert torch.equal(t[..., :4].permute(0, 3, 1, 2), F.interpolate(seg, size=(h, w_), mode="nearest")) and float(t[..., 4:].abs().max()) == 0
+    # orientation-loss tail and its gradient vs autograd through the reference's formula
+    conf_raw = torch.randn(2, 16, 12, generator=g, dtype=torch.float64).float().requires_grad_()
+    idx = torch.randint(0, 32, (2, 16, 12), generator=g, dtype=torch.uint8)
+    label = torch.randn(2, 2, 16, 12, generator=g)
+    hair = torch.zeros(2, 1, 16, 12)
+    hair[:, :, 3:13, 2:9] = 1
+    sem = torch.cat([1 - hair, hair], dim=1)
+    confidence = ((torch.tanh(conf_raw) + 1) / 2.0).unsqueeze(1)
+    ang = (idx.float() * (math.pi / 32)).unsqueeze(1)
+    fake = torch.cat([torch.sin(2 * ang), torch.cos(2 * ang)], dim=1) * confidence
+    want_o = F.l1_loss(fake * hair, (label * hair).detach())
+    want_c = -torch.sum(torch.log(torch.clamp(confidence, 0.001, 1)) * hair) / torch.sum(hair)
+    gw, = torch.autograd.grad(want_o * 2 + want_c * 0.5, conf_raw)
+    cr2 = conf_raw.detach().clone().requires_grad_()
+    lo, lc = ops.orient_loss(cr2, idx, label, sem[:, 1])
+    gg, = torch.autograd.grad(lo * 2 + lc * 0.5, cr2)
+    assert abs(float(lo) - float(want_o)) < 1e-6 and abs(float(lc) - float(want_c)) < 1e-6
+    assert (gg - gw).abs().max() < 1e-6 * max(1.0, float(gw.abs().max()))
