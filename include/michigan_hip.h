@@ -137,6 +137,13 @@ int mg_conv_wgrad(const mg_wgrad_desc* d, void* stream);
 int64_t mg_stats_workspace(int32_t G, int64_t P, int32_t C);
 int mg_channel_stats(const void* x, int32_t dtype, int32_t G, int64_t P, int32_t C,
                      float* sums /* [G][2][C] */, void* partial, void* stream);
+/* mg_channel_stats followed by mg_norm_finalize in TWO launches instead of three (stage 2 finalizes): for statistics that need no
+ * cross-rank reduction in between (instance norm; batch norm on one GPU).  sums are multiplied by sum_scale before use (4 for the
+ * statistics of a nearest 2x upsample taken from its source, `count` then counts the upsampled elements).  Bit-identical to
+ * mg_channel_stats + (sums *= sum_scale) + mg_norm_finalize. */
+int mg_channel_stats_finalize(const void* x, int32_t dtype, int32_t G, int64_t P, int32_t C, float sum_scale, double count,
+                              float eps, float momentum, float* running_mean, float* running_var,
+                              float* sums, float* mean, float* rstd, void* partial, void* stream);
 
 /* sums[G][2][C] + element count -> mean[G][C], rstd[G][C] = 1/sqrt(biased_var + eps) (fp64 inside); when
  * running_mean/var are given (G == 1) they are updated with momentum and the UNBIASED variance, as

@@ -483,6 +483,60 @@ __global__ __launch_bounds__(NTHR) void norm_bwd_apply2_vec(const mg_norm_apply2
     }
 }
 
+// stage 2 + finalize in one launch (no cross-rank reduction between them: instance norm, single-GPU batch norm): a block owns 16
+// channels; lanes 0..15 of each thread row sum the channels' partial sums, lanes 16..31 their partial sums of squares (fp64, fixed
+// order: the same values reduce_stage2 produces), then lanes 0..15 run norm_finalize_kernel's arithmetic on the fp32-rounded sums --
+// bit-identical to the two-launch path.  sum_scale: the statistics of a nearest 2x upsample from its source (x 4, exact).
+__global__ __launch_bounds__(256) void reduce_stage2_finalize(const float* __restrict__ partial, float* __restrict__ sums, int nchunks, int C,
+                                                              float sum_scale, double count, float eps, float momentum,
+                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                              float* __restrict__ mean, float* __restrict__ rstd)
+{
+    __shared__ double red[256];
+    __shared__ float fin[32];
+    const int cl = threadIdx.x & 31, kk = threadIdx.x >> 5;
+    const int c = blockIdx.x * 16 + (cl & 15);
+    const int g = blockIdx.y;
+    const int C2 = 2 * C;
+    const int i = (cl >> 4) * C + c;                            // column of the [sum | sum of squares] vector
+    double a = 0.0;
+    if (c < C) {
+        const float* p = partial + (size_t)g * nchunks * C2 + i;
+        int k = kk;
+        for (; k + 56 < nchunks; k += 64) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = p[(size_t)(k + 8 * j) * C2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += (double)v[j];
+        }
+        for (; k < nchunks; k += 8) a += (double)p[(size_t)k * C2];
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (kk == 0) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) a += red[r * 32 + cl];
+        const float f = (float)a * sum_scale;
+        fin[cl] = f;
+        if (c < C) sums[(size_t)g * C2 + i] = f;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && c < C) {
+        const double s = fin[threadIdx.x], ss = fin[16 + threadIdx.x];
+        const double m = s / count;
+        double var = ss / count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[(size_t)g * C + c] = (float)m;
+        rstd[(size_t)g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
 template <typename T, int MODE>
 int run_reduce(const void* x, const void* dh, const void* h, const void* g1, const float* mean, const float* rstd,
                void* dgb, int G, int64_t P, int C, float* sums, void* partial, int act, float slope, hipStream_t st,
@@ -529,6 +583,34 @@ extern "C" int mg_channel_stats(const void* x, int32_t dtype, int32_t G, int64_t
     if (dtype == MG_BF16)
         return run_reduce<uint16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, G, P, C, sums, partial, 0, 0.f, st);
     return run_reduce<float, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, G, P, C, sums, partial, 0, 0.f, st);
+}
+
+extern "C" int mg_channel_stats_finalize(const void* x, int32_t dtype, int32_t G, int64_t P, int32_t C, float sum_scale, double count,
+                                         float eps, float momentum, float* running_mean, float* running_var,
+                                         float* sums, float* mean, float* rstd, void* partial, void* stream)
+{
+    MG_CHECK_NORM_GEOM("mg_channel_stats_finalize");
+    MG_CHECK_ARG(x && sums && mean && rstd && partial, "mg_channel_stats_finalize: null pointer");
+    MG_CHECK_ARG(count > 0 && sum_scale > 0.f, "mg_channel_stats_finalize: bad count / scale");
+    MG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr) && (running_mean == nullptr || G == 1),
+                 "mg_channel_stats_finalize: running statistics need both buffers and G == 1");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const StatGeom sg = stat_geom(G, P, C);
+    dim3 grid(sg.nchunks, G);
+    if (dtype == MG_BF16) {
+        if (vec_geom_ok<uint16_t>(C)) hipLaunchKernelGGL((stats_stage1_vec<uint16_t, 4>), grid, dim3(NTHR), 0, st, (const uint16_t*)x, (float*)partial, P, C, sg.chunk);
+        else hipLaunchKernelGGL((reduce_stage1<uint16_t, 0, true>), grid, dim3(NTHR), 0, st, (const uint16_t*)x, (const uint16_t*)nullptr, (const uint16_t*)nullptr,
+                                (const uint16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (uint16_t*)nullptr, (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, 0, 0.f, 0, 0, 0);
+    } else {
+        if (vec_geom_ok<float>(C)) hipLaunchKernelGGL((stats_stage1_vec<float, 4>), grid, dim3(NTHR), 0, st, (const float*)x, (float*)partial, P, C, sg.chunk);
+        else hipLaunchKernelGGL((reduce_stage1<float, 0, true>), grid, dim3(NTHR), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr,
+                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, 0, 0.f, 0, 0, 0);
+    }
+    MG_CHECK_LAUNCH("mg_channel_stats_finalize(stage 1)");
+    hipLaunchKernelGGL(reduce_stage2_finalize, dim3((C + 15) / 16, G), dim3(256), 0, st, (const float*)partial, sums, sg.nchunks, C, sum_scale, count,
+                       eps, momentum, running_mean, running_var, mean, rstd);
+    MG_CHECK_LAUNCH("mg_channel_stats_finalize(stage 2)");
+    return MG_OK;
 }
 
 extern "C" int mg_norm_act_fwd(const void* x, void* y, int32_t dtype, int32_t G, int64_t P, int32_t C,

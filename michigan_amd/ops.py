@@ -575,14 +575,18 @@ def batch_stats_begin(x: torch.Tensor, up: bool = False):
         c = x.shape[-1]
         count = x.numel() // c * (4 if up else 1)
         src = getattr(x, "_mg_stats_src", None) if STATS_FROM_UPSAMPLE_SOURCE else None
+        # x = nearest 2x upsample of src (upsample2x) / up=True: every source value occurs exactly four times, so
+        # sum(x) = 4 sum(src) and sum(x^2) = 4 sum(src^2) -- reduce the quarter-size tensor (x4 is exact in fp32)
+        scale = 1.0
         if up:
-            sums = channel_sums(x).mul_(4.0)
+            scale = 4.0
         elif src is not None and src.shape[-1] == c and 4 * src.numel() == x.numel():
-            # x = nearest 2x upsample of src (upsample2x): every source value occurs exactly four times, so
-            # sum(x) = 4 sum(src) and sum(x^2) = 4 sum(src^2) -- reduce the quarter-size tensor (x4 is exact in fp32)
-            sums = channel_sums(src).mul_(4.0)
-        else:
-            sums = channel_sums(x)
+            x, scale = src, 4.0
+        if SYNC_BN_GROUP is None and FUSED_STATS_FINALIZE:
+            return ("fused", x, scale), None, count, c          # no cross-rank reduction: statistics + finalize in one entry (batch_stats_finish)
+        sums = channel_sums(x)
+        if scale != 1.0:
+            sums.mul_(scale)
         work = None
         if SYNC_BN_GROUP is not None:
             import torch.distributed as dist
@@ -592,11 +596,32 @@ def batch_stats_begin(x: torch.Tensor, up: bool = False):
         return sums, work, count, c
 
 
+FUSED_STATS_FINALIZE = True      # A/B switch: mg_channel_stats_finalize (2 launches) instead of stats + [x 4] + finalize (3-4)
+
+
+def stats_finalize(x: torch.Tensor, groups: int, count: float, eps: float, momentum: float = 0.0, running_mean=None, running_var=None,
+                   sum_scale: float = 1.0):
+    """(mean, rstd, sums) of x viewed as [G, P, C] with the finalize arithmetic fused into the second reduction stage."""
+    c = x.shape[-1]
+    p = x.numel() // (groups * c)
+    be = C.backend()
+    ws = torch.empty(max(int(be.mg_stats_workspace(groups, p, c)), 4), dtype=torch.uint8, device=x.device)
+    sums = torch.empty((groups, 2, c), dtype=torch.float32, device=x.device)
+    mean = torch.empty((groups, c), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((groups, c), dtype=torch.float32, device=x.device)
+    be.mg_channel_stats_finalize(_p(x), _dt(x), groups, p, c, float(sum_scale), float(count), eps, momentum, _p(running_mean), _p(running_var),
+                                 _p(sums), _p(mean), _p(rstd), _p(ws), _stream(x))
+    return mean, rstd, sums
+
+
 def batch_stats_finish(pending, eps: float = 1e-5, momentum: float = 0.1,
                        running_mean: Optional[torch.Tensor] = None, running_var: Optional[torch.Tensor] = None):
     """Second half: wait for the reduction (a stream dependency, not a host block, on RCCL) and finalize."""
     sums, work, count, c = pending
     with torch.no_grad():
+        if isinstance(sums, tuple):                              # ("fused", x, scale)
+            mean, rstd, sums = stats_finalize(sums[1], 1, count, eps, momentum, running_mean, running_var, sums[2])
+            return mean.reshape(c), rstd.reshape(c), count, sums
         if work is not None:
             work.wait()
         mean = torch.empty(c, dtype=torch.float32, device=sums.device)
@@ -952,10 +977,13 @@ class _InstanceNormActFn(torch.autograd.Function):
         x = _nhwc(x)
         n, h, w, c = x.shape
         p = h * w
-        sums = channel_sums(x, groups=n)
-        mean = torch.empty((n, c), dtype=torch.float32, device=x.device)
-        rstd = torch.empty((n, c), dtype=torch.float32, device=x.device)
-        C.backend().mg_norm_finalize(_p(sums), n, c, float(p), eps, 0.0, None, None, _p(mean), _p(rstd), _stream(x))
+        if FUSED_STATS_FINALIZE:
+            mean, rstd, _ = stats_finalize(x, n, float(p), eps)
+        else:
+            sums = channel_sums(x, groups=n)
+            mean = torch.empty((n, c), dtype=torch.float32, device=x.device)
+            rstd = torch.empty((n, c), dtype=torch.float32, device=x.device)
+            C.backend().mg_norm_finalize(_p(sums), n, c, float(p), eps, 0.0, None, None, _p(mean), _p(rstd), _stream(x))
         y = torch.empty_like(x)
         C.backend().mg_norm_act_fwd(_p(x), _p(y), _dt(x), n, p, c, _p(mean), _p(rstd), act, slope, _stream(x))
         ctx.save_for_backward(x, y, mean, rstd)
@@ -1378,7 +1406,11 @@ class _PixelAffineFn(torch.autograd.Function):
             dx = torch.empty_like(g)
             C.backend().mg_pixel_affine(_p(g), _p(a), None, None, _dt(g), g.numel() // c, c, _p(dx), _stream(g))
         if ctx.needs_input_grad[2]:
-            dbias = torch.mv(g.reshape(-1, c).float().t(), b.reshape(-1)).to(ctx.bias_dtype)       # sum_p g[p, c] * b[p]
+            # sum_p g[p, c] * b[p]: mask the gradient (b is the 0/1 update mask: exact in any dtype) and take the deterministic two-stage
+            # channel sums -- a gemv over the [P, C] gradient ran 1.1 ms per layer in rocBLAS (P = 524288 rows)
+            gm = torch.empty_like(g)
+            C.backend().mg_pixel_affine(_p(g), _p(b), None, None, _dt(g), g.numel() // c, c, _p(gm), _stream(g))
+            dbias = channel_sums(gm)[0, 0].to(ctx.bias_dtype)
         return dx, None, dbias, None
 
 

@@ -155,6 +155,12 @@ class EmulatorBackend:
         s[:, 1] = (xv * xv).sum(1).float()
         return 0
 
+    def mg_channel_stats_finalize(self, x, dtype, G, P, C, sum_scale, count, eps, momentum, running_mean, running_var, sums, mean, rstd,
+                                  partial, stream=None):
+        self.mg_channel_stats(x, dtype, G, P, C, sums, partial)
+        _view(sums, (G, 2, C), torch.float32).mul_(sum_scale)
+        return self.mg_norm_finalize(sums, G, C, count, eps, momentum, running_mean, running_var, mean, rstd)
+
     def mg_norm_finalize(self, sums, G, C, count, eps, momentum, running_mean, running_var, mean, rstd, stream=None):
         s = _view(sums, (G, 2, C), torch.float32).double()
         m = s[:, 0] / count

@@ -31,13 +31,26 @@ def _golden(tag):
     return np.load(os.path.join(GOLDEN, "trainer_%s.npz" % tag))
 
 
-@pytest.fixture
-def dropin_installed(emulator_backend):
+@pytest.fixture(params=["emulator", "hip"])
+def dropin_installed(request):
+    """The reference's classes patched by dropin.install(), on the contract emulator (CPU suite) and -- wherever a GPU and the
+    reference checkout coexist -- on the real HIP kernels (the GPU box of the driver has no reference checkout: skipped there)."""
+    from michigan_amd import _cabi
+    if request.param == "hip":
+        if not torch.cuda.is_available():
+            pytest.skip("needs a GPU next to the reference checkout")
+        prev = _cabi.set_backend(None)
+        assert _cabi.backend().name == "hip"
+    else:
+        from oracle.cabi_emulator import EmulatorBackend
+        prev = _cabi.set_backend(EmulatorBackend())
     R.setup()
     import michigan_amd.dropin as dropin
     patched = dropin.install(compute_dtype="fp32")
+    patched["_backend"] = request.param
     yield patched
     dropin.uninstall()
+    _cabi.set_backend(prev)
 
 
 @needs_reference
@@ -82,8 +95,12 @@ def test_reference_trainer_over_hip_classes_matches_reference_golden(dropin_inst
     cfg = TP.CFGS[tag]
     from trainers.pix2pix_trainer import Pix2PixTrainer
     from michigan_amd import networks as hip
+    on_gpu = dropin_installed["_backend"] == "hip"
     with tempfile.TemporaryDirectory() as ck:
-        opt = R.reference_options(TP.reference_argv(cfg, ck), train=True)
+        argv = TP.reference_argv(cfg, ck)
+        if on_gpu:
+            argv[argv.index("--gpu_ids") + 1] = "0"
+        opt = R.reference_options(argv, train=True)
         assert opt.norm_G == "spectralspadesyncbatch3x3"              # set by the HIP generator's modify_commandline_options
         if cfg["use_ig"]:
             R.write_inpaint_checkpoint(opt, seed=cfg["seed_ig"], gain=cfg["gain"])
@@ -96,8 +113,9 @@ def test_reference_trainer_over_hip_classes_matches_reference_golden(dropin_inst
         if cfg["use_ig"]:
             assert isinstance(m.netIG, hip.InpaintGenerator)
         TP.load_weights(trainer, cfg)
-        rec = TP.drive(trainer, cfg)
-    TP.compare(rec, _golden(tag), **TOL)
+        rec = TP.drive(trainer, cfg, device="cuda" if on_gpu else "cpu")
+    # HIP fp32 kernels: the single-GPU tolerances of tests/test_gpu_trainer.py
+    TP.compare(rec, _golden(tag), **(dict(TOL, rtol_loss0=5e-4, atol_img=1e-3) if on_gpu else TOL))
 
 
 @pytest.mark.parametrize("tag", ["A", "B"])
@@ -175,7 +193,11 @@ def test_config0_reference_inference_over_hip_classes(dropin_installed):
     from michigan_amd.synth import synth_state_dict
     data, fx, cfg = PU.config0_fixture()
     with tempfile.TemporaryDirectory() as ck:
-        opt = R.reference_options(R.README_INFERENCE_FLAGS + ["--data_dir", "unused", "--checkpoints_dir", ck], train=False)
+        argv = list(R.README_INFERENCE_FLAGS) + ["--data_dir", "unused", "--checkpoints_dir", ck]
+        on_gpu = dropin_installed["_backend"] == "hip"
+        if on_gpu:
+            argv = (argv[:argv.index("--gpu_ids")] + argv[argv.index("--gpu_ids") + 2:] if "--gpu_ids" in argv else argv) + ["--gpu_ids", "0"]
+        opt = R.reference_options(argv, train=False)
         R.write_inpaint_checkpoint(opt, seed=cfg["seed_ig"], gain=cfg["gain"])
         torch.manual_seed(0)
         model = Pix2PixModel(opt)
@@ -184,7 +206,7 @@ def test_config0_reference_inference_over_hip_classes(dropin_installed):
     model.eval()
     with torch.no_grad():
         out = model(data, mode="inference")
-    PU.compare_config0(out, fx, cfg, atol=2e-4, rtol_sum=1e-5)
+    PU.compare_config0(out, fx, cfg, atol=1e-3 if on_gpu else 2e-4, rtol_sum=1e-4 if on_gpu else 1e-5)
 
 
 def test_checkpoint_round_trip_resumes_exactly(emulator_backend, tmp_path):

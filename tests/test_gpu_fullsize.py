@@ -182,3 +182,49 @@ def test_generator_bf16_default_init_matches_oracle_tightly(hip_backend):
     print("bf16 default-init generator: L_inf %.3e mean %.3e, image range %.3e" % (err.max().item(), err.mean().item(), rng))
     assert err.max().item() < 1e-2 and err.mean().item() < 5e-4
     assert err.max().item() < 6e-2 * rng
+
+
+def test_generator_fullwidth_bf16_gradients_track_fp32_oracle(hip_backend):
+    """VERDICT r2 parity hole: the full-width gradient test above is fp32, so it runs `wgrad_kernel`; the BENCHMARKED weight-gradient
+    kernel (`wgrad3x3_kernel`, bf16 only, split-K over 1024 / 512 channels) was covered at <= 256 channels.  Here: bf16 forward +
+    backward at ngf 64, 256x256, batch 2 under the reference default init (the benchmarked configuration) against torch autograd
+    through the fp32 oracle, for the same 11 parameters.  bf16 activations carry 2^-9 relative rounding through ~40 layers each way,
+    so the comparison is directional: cosine similarity >= 0.99 and relative L2 error <= 0.15 per tensor (printed; measured values in
+    DESIGN.md section 5)."""
+    from michigan_amd import networks
+    from michigan_amd.model import default_options
+    from michigan_amd.optim import FlatAdam
+    from michigan_amd.synth import synth_batch
+    from oracle import michigan_oracle as O
+    names = ["head_0.conv_0.weight_orig", "G_middle_1.conv_1.weight_orig", "up_0.conv_0.weight_orig", "up_0.conv_s.weight_orig",
+             "up_0.norm_0.mlp_gamma.weight", "up_1.norm_1.mlp_beta.weight", "head_0.norm_1.mlp_gamma.bias", "fc.layer5.weight",
+             "up_3.conv_1.bias", "up_2.norm_s.mlp_shared.0.weight", "backgroud_enc.layer3.conv.weight"]
+    opt = default_options(gpu_ids=[0], compute_dtype="bf16", random_expand_mask=False, crop_size=256)
+    torch.manual_seed(11)
+    G = networks.SPADEBGenerator(opt).train()
+    G.init_weights(opt.init_type, opt.init_variance)
+    sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    G.cuda().set_compute_dtype(torch.bfloat16)
+    optim = FlatAdam(G.parameters(), lr=1e-4)                 # the benchmarked path: gradient sink -> wgrad3x3_kernel into the GEMM-order arena
+    b = synth_batch(2, 256, seed=79)
+    gy = torch.randn(2, 3, 256, 256, generator=torch.Generator().manual_seed(5))
+    optim.zero_grad()
+    out = _run(G, b, 2)
+    (out.float() * gy.cuda()).sum().backward()
+    optim.finalize_grads()
+    got = {n: p.grad.detach().float().cpu().clone() for n, p in G.named_parameters() if n in names}
+    assert sorted(got) == sorted(names)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    osd = {k: (v.clone().requires_grad_() if k in names else v.clone()) for k, v in sd.items()}
+    ref_out = O.spadeb_generator(osd, opt, b["input_ref"], b["orient"], b["image_ref"], b["input_tag"], b["noise"], b["image_tag"], True, {})
+    (ref_out * gy).sum().backward()
+    report, bad = {}, {}
+    for n in names:
+        a, r = got[n].double().flatten(), osd[n].grad.double().flatten()
+        cos = float(torch.dot(a, r) / (a.norm() * r.norm() + 1e-300))
+        rel = float((a - r).norm() / (r.norm() + 1e-300))
+        report[n] = "cos %.5f rel-L2 %.2e" % (cos, rel)
+        if not (cos >= 0.99 and rel <= 0.15):
+            bad[n] = report[n]
+    print("full-width bf16 gradients vs fp32 oracle:", report)
+    assert not bad, bad
