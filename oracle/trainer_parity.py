@@ -37,6 +37,13 @@ G_BUFFERS = ("up_3.norm_0.param_free_norm.running_mean", "up_3.norm_0.param_free
              "up_3.conv_0.weight_u", "head_0.conv_1.weight_v", "up_0.conv_s.weight_u")
 D_BUFFERS = ("discriminator_0.model1.0.0.weight_u", "discriminator_1.model3.0.0.weight_v")
 LOSS_KEYS = ("GAN", "GAN_Feat", "VGG", "ORIENT", "D_Fake", "D_real")
+# Tolerance for everything behind an optimiser step on the HIP fp32 kernels.  tools/noise_probe.py (profiles/r03_noise_probe.txt) runs
+# the protocol twice on MI355X with two kernel pipelines that differ ONLY in fp32 accumulation order: the two runs land 4.2e-2 apart in the
+# running statistics of the last block and 4.9e-3 apart in the iteration-1 losses (Adam with beta1 = 0 is a sign function at the first
+# step), each 1.2e-2 ... 3.0e-2 from the reference's CPU run -- with identical iteration-0 results (2e-5).  1e-2 was inside that spread
+# and passed or failed with the rounding of unrelated kernels; 6e-2 is the spread plus a margin.  The deterministic float64 emulator runs
+# of the CPU suite keep 1e-2.
+RTOL_LATER_HIP = 6e-2
 
 
 def reference_argv(cfg, checkpoints_dir: str):
@@ -108,8 +115,9 @@ def compare(rec, gold, *, rtol_loss0, rtol_later, atol_img, atol_weight):
     Iteration 0 (forward, losses, generated image) is compared at `rtol_loss0` / `atol_img`: rounding-level agreement.
     Everything behind the first optimiser step is compared at `rtol_later`: Adam with beta1 = 0 (TTUR, pix2pix_model.py:137-
     145) makes its first update lr * g / |g| -- a sign function -- so a gradient that differs in its last bits around zero
-    moves that weight by 2 * lr in the other direction; a few such weights shift iteration-1 losses and the running
-    statistics by ~1e-3 relative in ANY two correct implementations (the reference on two BLAS builds included).
+    moves that weight by 2 * lr in the other direction; such weights shift iteration-1 losses and the running statistics in
+    ANY two correct implementations (the reference on two BLAS builds included) -- measured on MI355X between two fp32
+    kernel pipelines: up to 5e-3 on the losses and 4e-2 on the running statistics (RTOL_LATER_HIP above).
     Weights themselves: at most 1 % of a tensor's elements may be further than `atol_weight` (stated in units of lr)."""
     bad = []
     for k in gold.files:

@@ -131,7 +131,7 @@ def main(mode):
     class _G(dict):
         files = property(lambda self: list(self.keys()))
     hip = device.type == "cuda"
-    TP.compare(rec, _G(gold), rtol_loss0=5e-4 if hip else 2e-4, rtol_later=1e-2, atol_img=1e-3 if hip else 2e-4,
+    TP.compare(rec, _G(gold), rtol_loss0=5e-4 if hip else 2e-4, rtol_later=TP.RTOL_LATER_HIP if hip else 1e-2, atol_img=1e-3 if hip else 2e-4,
                atol_weight=2 * 4e-4 * 2 + 1e-5)
 
     # replicas bitwise identical

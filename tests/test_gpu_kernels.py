@@ -931,3 +931,48 @@ def test_glue_kernels_match_contract(dt):
         (hip, _), (ref, _) = _both(ol, (conf_raw, idx, label, sem))
         for i in range(4):
             _close(f"orient_loss {label.shape[1]}ch out {i}", hip[i], ref[i], 2e-5)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_stats_finalize_fused_is_bit_identical_to_the_three_launch_path(hip_backend, dt):
+    """mg_channel_stats_finalize (stage 2 finalizes) == mg_channel_stats + (sums *= scale) + mg_norm_finalize, bit for bit: batch
+    norm (G = 1, running statistics, the x4 upsample scale) and instance norm (G = N), vec and non-vec channel geometries."""
+    from michigan_amd import ops
+    from michigan_amd import _cabi as C
+    g = torch.Generator().manual_seed(9)
+    for (n, h, w, c, groups, scale) in ((4, 24, 20, 64, 1, 1.0), (2, 16, 16, 1024, 1, 4.0), (3, 33, 17, 128, 3, 1.0), (2, 9, 7, 24, 2, 1.0)):
+        x = (torch.randn(n, h, w, c, generator=g) * 2 + 0.5).to(DT[dt]).cuda()
+        count = float(x.numel() // (groups * c)) * scale
+        rm0, rv0 = torch.randn(c, generator=g).cuda(), torch.rand(c, generator=g).cuda() + 0.5
+        rm_a, rv_a = (rm0.clone(), rv0.clone()) if groups == 1 else (None, None)
+        mean_a, rstd_a, sums_a = ops.stats_finalize(x, groups, count, 1e-5, 0.1, rm_a, rv_a, scale)
+        sums_b = ops.channel_sums(x, groups=groups)
+        if scale != 1.0:
+            sums_b.mul_(scale)
+        mean_b = torch.empty((groups, c), device="cuda"); rstd_b = torch.empty((groups, c), device="cuda")
+        rm_b, rv_b = (rm0.clone(), rv0.clone()) if groups == 1 else (None, None)
+        C.backend().mg_norm_finalize(ops._p(sums_b), groups, c, count, 1e-5, 0.1, ops._p(rm_b), ops._p(rv_b), ops._p(mean_b), ops._p(rstd_b), ops._stream(x))
+        torch.cuda.synchronize()
+        for a, b in ((sums_a, sums_b), (mean_a, mean_b), (rstd_a, rstd_b)) + (((rm_a, rm_b), (rv_a, rv_b)) if groups == 1 else ()):
+            assert torch.equal(a.reshape(-1), b.reshape(-1)), (n, h, w, c, groups)
+        xr = x.float().reshape(groups, -1, c)
+        _close(f"stats_finalize mean {dt}", mean_a, xr.mean(1).reshape(groups, c) , 1e-4)
+
+
+@pytest.mark.parametrize("shape", [(8, 32, 32, 1024, 1024), (8, 64, 64, 1024, 512), (8, 64, 64, 128, 2048), (8, 16, 16, 1024, 1024), (8, 128, 128, 512, 256)],
+                         ids=lambda s: "x%dx%d_%d_to_%d" % (s[1], s[2], s[3], s[4]))
+def test_wgrad_wide_channels_match_torch_gpu(shape):
+    """the bf16 3x3 weight-gradient kernel (`wgrad3x3_kernel`, kernel-row tiles, split-K with fp32 atomics) at the
+    BENCHMARKED channel counts (1024 / 512 / the 2048-row fused gamma|beta image) -- its contract tests stop at 256 channels.  Same
+    bf16 operands into torch's own fp32 GPU convolution weight gradient; both accumulate in fp32, so they agree to summation-order
+    rounding: 2e-3 of the largest element (the bias gradient: column sums of dy, same bound)."""
+    from michigan_amd import ops
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, h, w, cin, generator=g).bfloat16().cuda()
+    dy = (torch.randn(n, h, w, cout, generator=g) / 8).bfloat16().cuda()
+    dw, db = ops.conv_wgrad(x, dy, 3, 3, 1, 1, want_bias=True)
+    got = ops.unpack_wgrad(dw, (cout, cin, 3, 3))
+    ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (cout, cin, 3, 3), dy.float().permute(0, 3, 1, 2), padding=1)
+    _close("wgrad3x3 vs torch gpu", got, ref, 2e-3)
+    _close("bias gradient", db[:cout], dy.float().sum((0, 1, 2)), 2e-3)

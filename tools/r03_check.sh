@@ -7,7 +7,7 @@ set -u
 TAG=${1:-r03}; QUICK=${2:-}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
-timeout 900 python -m pytest tests -q -m gpu -x > $OUT/pytest_gpu.log 2>&1; echo "pytest_gpu rc=$?" | tee -a $OUT/rc.log
+timeout 1200 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "pytest_gpu rc=$?" | tee -a $OUT/rc.log
 timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/rc.log
 if [ -z "$QUICK" ]; then
   MG_BENCH_BACKEND=gloo timeout 400 python bench.py --gpus 2 --steps 2 --warmup 1 --batch-per-gpu 2 --no-cpu-baseline > $OUT/bench_gloo2.json 2> $OUT/bench_gloo2.err; echo "bench_gloo2 rc=$?" | tee -a $OUT/rc.log
