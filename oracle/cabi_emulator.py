@@ -82,11 +82,11 @@ class EmulatorBackend:
 
     # -- bookkeeping ---------------------------------------------------------
     def mg_abi_version(self):
-        return 2
+        return 3
 
     def mg_sizeof_desc(self, which):
         from michigan_amd import _cabi
-        return ctypes.sizeof((_cabi.ConvDesc, _cabi.WgradDesc, _cabi.GradSlot, _cabi.PackJob, _cabi.SnLayer, _cabi.NormApply2Desc)[which])
+        return ctypes.sizeof((_cabi.ConvDesc, _cabi.WgradDesc, _cabi.GradSlot, _cabi.PackJob, _cabi.SnLayer, _cabi.NormApply2Desc, _cabi.PyramidDesc)[which])
 
     def mg_last_error(self):
         return b""
