@@ -121,9 +121,16 @@ typedef struct mg_wgrad_desc {
     int32_t flags;         /* bit0: bf16 operands via ds_read_b64_tr_b16      */
     int8_t  tap_dy[MG_MAX_TAPS];
     int8_t  tap_dx[MG_MAX_TAPS];
+    void*   det_ws;        /* optional: deterministic split-K workspace (see below), NULL = fp32 atomics */
+    int64_t det_ws_bytes;
 } mg_wgrad_desc;
 
-int mg_conv_wgrad(const mg_wgrad_desc* d, void* stream);
+/* Split-K partial sums reach dw / dbias through fp32 atomics by default (their order, hence the last bits, vary from run to run).
+ * With det_ws != NULL every split stores its partial tile into its own slab of the workspace instead and a finishing launch adds the
+ * slabs to dw / dbias in a fixed order: bit-reproducible, one extra pass over splits x |dw|.  mg_wgrad_det_workspace returns the bytes
+ * the launch mg_conv_wgrad(d) would need (it depends on the split count the launcher picks). */
+int     mg_conv_wgrad(const mg_wgrad_desc* d, void* stream);
+int64_t mg_wgrad_det_workspace(const mg_wgrad_desc* d);
 
 /* ---------------------------------------------------------------------------
  * Per-channel statistics (sync-BN / instance-norm reduce).

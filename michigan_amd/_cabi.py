@@ -42,6 +42,7 @@ class WgradDesc(ctypes.Structure):
         ("Hj", _i32), ("Wj", _i32), ("Cg", _i32), ("isy", _i32), ("isx", _i32),
         ("ntaps", _i32), ("splitk", _i32), ("flags", _i32),
         ("tap_dy", ctypes.c_int8 * MG_MAX_TAPS), ("tap_dx", ctypes.c_int8 * MG_MAX_TAPS),
+        ("det_ws", _vp), ("det_ws_bytes", _i64),
     ]
 
 
@@ -88,6 +89,7 @@ class SnLayer(ctypes.Structure):
 _PROTOS = {
     "mg_conv_taps": ([ctypes.POINTER(ConvDesc), _vp], _i32),
     "mg_conv_wgrad": ([ctypes.POINTER(WgradDesc), _vp], _i32),
+    "mg_wgrad_det_workspace": ([ctypes.POINTER(WgradDesc)], _i64),
     "mg_stats_workspace": ([_i32, _i64, _i32], _i64),
     "mg_channel_stats": ([_vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp], _i32),
     "mg_channel_stats_finalize": ([_vp, _i32, _i32, _i64, _i32, _f32, ctypes.c_double, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i32),
@@ -156,7 +158,7 @@ _PROTOS = {
     "mg_last_error": ([], ctypes.c_char_p),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS)
-_NO_STATUS = {"mg_norm_apply2_supported", "mg_grad_slot_blocks", "mg_pack_job_blocks", "mg_sn_layer_blocks", "mg_stats_workspace", "mg_sizeof_desc", "mg_abi_version", "mg_last_error", "mg_noise_field_len", "mg_bicubic_ksize"}
+_NO_STATUS = {"mg_wgrad_det_workspace", "mg_norm_apply2_supported", "mg_grad_slot_blocks", "mg_pack_job_blocks", "mg_sn_layer_blocks", "mg_stats_workspace", "mg_sizeof_desc", "mg_abi_version", "mg_last_error", "mg_noise_field_len", "mg_bicubic_ksize"}
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmichigan_hip.so")
 

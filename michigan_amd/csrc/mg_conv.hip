@@ -15,7 +15,7 @@
 // pipe).  bf16 uses v_mfma_f32_32x32x16_bf16, f32 uses v_mfma_f32_32x32x2_f32
 // (exact fp32 fma chain) -- same tiling, same LDS image (64 B of K per row).
 
-int g_mg_conv_splitk_wide = 1;   // ... also for launches of 161..320 workgroups with >= 256 K steps (mg_set_option(17, v), A/B)
+int g_mg_conv_splitk_wide = 0;   // ... also for launches of 161..320 workgroups with >= 256 K steps (mg_set_option(17, 1)): measured flat, off
 int g_mg_conv_splitk = 1;        // deterministic split-K for low-resolution long-K layers (mg_set_option(5, v))
 int g_mg_conv_halo_ring = 3;     // weight-slab ring of the big halo tile: 3 = two taps in flight, 4 = three (mg_set_option(9, v)); measured equal (profiles/r02_halo_ring_ab.txt)
 int g_mg_conv_halo_big = 1;      // 128 channels x 16x16 pixel halo tiles where the launch is big enough (mg_set_option(4, v))
@@ -446,8 +446,8 @@ int launch_conv_p(ConvK& k, hipStream_t st)
             // in a fixed order (deterministic) and applies bias / residual / activation.
             if constexpr (EPI == MG_EPI_PLAIN && !PACK && WM == 2 && WN == 2 && MT == 2 && NT == 2) {
                 const int nchunk = (k.Cin * (int)sizeof(T) + ROWB - 1) / ROWB, nkk = k.ntaps * nchunk;
-                // (nblk <= 160 until round 3; the 18432-deep gamma|beta data gradient at 64x64 -- 256 workgroups, one per CU, 576 K steps
-                // each -- ran at 760 TFLOP/s: two slices per tile give every CU a second workgroup to overlap with)
+                // (mg_set_option(17, 1) widens the rule to 161..320 workgroups with >= 256 K steps -- the 18432-deep gamma|beta data gradient at
+                // 64x64 runs 256 workgroups, one per CU, at 760 TFLOP/s; two slices per tile measured 69.35 vs 69.31 ms per step: flat, left off)
                 if (g_mg_conv_splitk && (nblk <= 160 || (nblk <= 320 && nkk >= 256 && g_mg_conv_splitk_wide)) && nkk >= 64 && (k.Cout & 3) == 0 && (k.Cout_gemm & 3) == 0) {
                     int S = (int)(((nblk <= 160 ? 384 : 512) + nblk - 1) / nblk);
                     if (S > nkk / 16) S = nkk / 16;

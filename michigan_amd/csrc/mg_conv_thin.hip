@@ -249,9 +249,10 @@ __global__ __launch_bounds__(256, 4) void wgrad3x3_thin_kernel(const Wg3K d, con
         }
     }
 
+    const int split = blockIdx.x * KG + kg;                      // deterministic mode: one slab per (workgroup, K group)
     if (d.dbias) {
         const float t = bsum + __shfl_xor(bsum, 32);             // the two K halves of the row
-        if (hi == 0) atomicAdd(d.dbias + mblk * 32 + l31, t);
+        if (hi == 0) wg_accum(d.dbias, d.det_stride, split, (size_t)(mblk * 32 + l31), t);
     }
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) {
@@ -260,14 +261,14 @@ __global__ __launch_bounds__(256, 4) void wgrad3x3_thin_kernel(const Wg3K d, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = mblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                atomicAdd(d.dw + ((size_t)(tap * d.Cg + co) * 8 + ci), acc[nb][r]);
+                wg_accum(d.dw, d.det_stride, split, (size_t)(tap * d.Cg + co) * 8 + ci, acc[nb][r]);
             }
         }
     }
 }
 
 template <int MB>
-int launch_wthin(Wg3K& k, hipStream_t st)
+int launch_wthin(Wg3K& k, hipStream_t st, int* nsplit, bool dry)
 {
     const int tiles_y = (k.H + WTH - 1) / WTH, tiles_x = k.W / THIN_TW;
     const long ntiles = (long)k.N * tiles_y * tiles_x;
@@ -275,6 +276,8 @@ int launch_wthin(Wg3K& k, hipStream_t st)
     // every workgroup ends with one pass of atomics over the whole dW: at least 4 tiles each, at most 2 per CU
     long grid = (ntiles + 3) / 4;
     if (grid > 512) grid = 512;
+    if (nsplit) *nsplit = (int)grid * (4 / MB);
+    if (dry) return MG_OK;
     const int lds = WHALO_BYTES + WTH * 32 * MB * 64;
     hipLaunchKernelGGL(wgrad3x3_thin_kernel<MB>, dim3((unsigned)grid), dim3(256), lds, st, k, (int)ntiles, tiles_y, tiles_x);
     MG_CHECK_LAUNCH("mg_conv_wgrad(thin)");
@@ -315,7 +318,7 @@ bool wgrad_thin_applies(const Wg3K& k)
            (long)k.N * ((k.H + WTH - 1) / WTH) * (k.W / THIN_TW) >= 64;
 }
 
-int launch_wgrad_thin(Wg3K& k, hipStream_t st)
+int launch_wgrad_thin(Wg3K& k, hipStream_t st, int* nsplit, bool dry)
 {
-    return k.Cg == 64 ? launch_wthin<2>(k, st) : launch_wthin<4>(k, st);
+    return k.Cg == 64 ? launch_wthin<2>(k, st, nsplit, dry) : launch_wthin<4>(k, st, nsplit, dry);
 }

@@ -28,6 +28,7 @@ struct WgK {
     int kper;         // pixels per split (multiple of KP)
     int tiles_m, tiles_n, splitk;
     int tpt;          // taps packed into one 128-wide N tile (Cin < 128 and 128 % Cin == 0), else 1
+    long det_stride;  // deterministic mode: floats per split slab (dw / dbias point into the workspace), 0 = fp32 atomics
     int tap[MG_MAX_TAPS];
 };
 
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgK d)
         if (tid < 128 && m0 + tid < d.Cg) {
             float t = 0.f;
             for (int r = 0; r < RPP; ++r) t += red[r * 128 + tid];
-            atomicAdd(d.dbias + m0 + tid, t);
+            wg_accum(d.dbias, d.det_stride, split, (size_t)(m0 + tid), t);
         }
     }
 
@@ -246,13 +247,25 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgK d)
             for (int r = 0; r < 16; ++r) {
                 const int co = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (co < d.Cg)
-                    atomicAdd(d.dw + ((size_t)(tap * d.Cg + co) * d.Cin + ci), acc[mt][nt][r]);
+                    wg_accum(d.dw, d.det_stride, split, (size_t)(tap * d.Cg + co) * d.Cin + ci, acc[mt][nt][r]);
             }
         }
 }
 
+// deterministic mode: dst[i] += sum over splits, in split order (fixed): dw for i < ndw, dbias behind it
+__global__ void wgrad_det_finish_kernel(const float* __restrict__ ws, int nsplit, long stride, float* __restrict__ dw, long ndw,
+                                        float* __restrict__ dbias, int nbias)
+{
+    const long total = ndw + nbias;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) a += ws[(size_t)sp * stride + i];
+        if (i < ndw) dw[i] += a; else dbias[i - ndw] += a;
+    }
+}
+
 template <typename T, bool TR>
-int launch_wgrad(WgK& k, hipStream_t st)
+int launch_wgrad(WgK& k, hipStream_t st, int* nsplit = nullptr, bool dry = false)
 {
     constexpr bool BF = (sizeof(T) == 2);
     constexpr int KP = BF ? 32 : 16;
@@ -272,6 +285,8 @@ int launch_wgrad(WgK& k, hipStream_t st)
     S = (k.K + k.kper - 1) / k.kper;
     k.splitk = S;
     const long nblk = base * S;
+    if (nsplit) *nsplit = S;
+    if (dry) return MG_OK;
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_wgrad: bad grid %ld", nblk);
     const size_t lds = 2 * 2 * (size_t)KP * RS;
     hipLaunchKernelGGL((wgrad_kernel<T, TR>), dim3((unsigned)nblk), dim3(NTHR), lds, st, k);
@@ -281,32 +296,37 @@ int launch_wgrad(WgK& k, hipStream_t st)
 
 }  // namespace
 
-extern "C" int mg_conv_wgrad(const mg_wgrad_desc* d, void* stream)
+int launch_wgrad_det_finish(const float* ws, int nsplit, long stride, float* dw, long ndw, float* dbias, int nbias, hipStream_t st)
 {
-    MG_CHECK_ARG(d != nullptr, "mg_conv_wgrad: null descriptor");
-    MG_CHECK_ARG(d->x && d->dy && d->dw, "mg_conv_wgrad: null tensor pointer");
-    MG_CHECK_ARG(d->dtype == MG_F32 || d->dtype == MG_BF16, "mg_conv_wgrad: bad dtype %d", d->dtype);
-    MG_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= MG_MAX_TAPS, "mg_conv_wgrad: ntaps=%d out of range", d->ntaps);
-    MG_CHECK_ARG(d->Cin > 0 && (d->Cin % 8) == 0 && d->Cg > 0 && (d->Cg % 8) == 0,
-                 "mg_conv_wgrad: Cin=%d / Cg=%d must be positive multiples of 8", d->Cin, d->Cg);
-    MG_CHECK_ARG(d->N > 0 && d->Hj > 0 && d->Wj > 0 && d->Hin > 0 && d->Win > 0, "mg_conv_wgrad: empty geometry");
-    MG_CHECK_ARG((long)d->N * d->Hj * d->Wj < (1L << 30), "mg_conv_wgrad: too many pixels");
+    const long total = ndw + nbias;
+    long grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(wgrad_det_finish_kernel, dim3((unsigned)grid), dim3(256), 0, st, ws, nsplit, stride, dw, ndw, dbias, nbias);
+    MG_CHECK_LAUNCH("mg_conv_wgrad(deterministic finish)");
+    return MG_OK;
+}
+
+namespace {
+
+// One routing function for the launch and for the workspace query: picks the kernel exactly as the launch would; with `dry` it only
+// reports the split count that kernel's launcher chooses.  det (dw_ws != nullptr): partial sums go to slabs of dw_ws.
+int route_wgrad(const mg_wgrad_desc* d, hipStream_t st, float* dw, float* dbias, long det_stride, int* nsplit, bool dry)
+{
     WgK k;
-    k.x = d->x; k.dy = d->dy; k.dw = d->dw; k.dbias = d->dbias;
+    k.x = d->x; k.dy = d->dy; k.dw = dw; k.dbias = dbias;
     k.N = d->N; k.Hin = d->Hin; k.Win = d->Win; k.Cin = d->Cin;
     k.Hj = d->Hj; k.Wj = d->Wj; k.Cg = d->Cg; k.isy = d->isy; k.isx = d->isx; k.ntaps = d->ntaps;
-    k.K = d->N * d->Hj * d->Wj; k.splitk = d->splitk; k.kper = 0; k.tiles_m = k.tiles_n = 0; k.tpt = 1;
+    k.K = d->N * d->Hj * d->Wj; k.splitk = d->splitk; k.kper = 0; k.tiles_m = k.tiles_n = 0; k.tpt = 1; k.det_stride = det_stride;
     for (int t = 0; t < MG_MAX_TAPS; ++t)
         k.tap[t] = t < d->ntaps ? (int)((((uint32_t)(int)d->tap_dy[t]) & 0xffffu) | (((uint32_t)(int)d->tap_dx[t]) << 16)) : 0;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == MG_BF16 && d->ntaps == 9 && d->isy == 1 && d->isx == 1 && d->Hin == d->Hj && d->Win == d->Wj && d->Cin == 8) {
         bool std3x3 = true;
         for (int t = 0; t < 9; ++t) std3x3 = std3x3 && d->tap_dy[t] == t / 3 - 1 && d->tap_dx[t] == t % 3 - 1;
         Wg3K k3;
-        k3.x = d->x; k3.dy = d->dy; k3.dw = d->dw; k3.dbias = d->dbias;
+        k3.x = d->x; k3.dy = d->dy; k3.dw = dw; k3.dbias = dbias;
         k3.N = d->N; k3.H = d->Hin; k3.W = d->Win; k3.Cin = d->Cin; k3.Cg = d->Cg;
-        k3.nstg = 0; k3.sps = 0; k3.tiles_m = k3.tiles_n = 0; k3.splitk = 0;
-        if (std3x3 && wgrad_thin_applies(k3)) return launch_wgrad_thin(k3, st);
+        k3.nstg = 0; k3.sps = 0; k3.tiles_m = k3.tiles_n = 0; k3.splitk = 0; k3.det_stride = det_stride;
+        if (std3x3 && wgrad_thin_applies(k3)) return launch_wgrad_thin(k3, st, nsplit, dry);
     }
     if (g_mg_wgrad3x3 && d->dtype == MG_BF16 && (d->flags & 1) && d->ntaps == 9 && d->isy == 1 && d->isx == 1 &&
         d->Hin == d->Hj && d->Win == d->Wj && (d->Win == 16 || d->Win % 32 == 0) && (d->Hin * d->Win) % 32 == 0 &&
@@ -315,13 +335,56 @@ extern "C" int mg_conv_wgrad(const mg_wgrad_desc* d, void* stream)
         for (int t = 0; t < 9; ++t) std3x3 = std3x3 && d->tap_dy[t] == t / 3 - 1 && d->tap_dx[t] == t % 3 - 1;
         if (std3x3) {
             Wg3K k3;
-            k3.x = d->x; k3.dy = d->dy; k3.dw = d->dw; k3.dbias = d->dbias;
+            k3.x = d->x; k3.dy = d->dy; k3.dw = dw; k3.dbias = dbias;
             k3.N = d->N; k3.H = d->Hin; k3.W = d->Win; k3.Cin = d->Cin; k3.Cg = d->Cg;
-            k3.nstg = k.K / 32; k3.sps = 0; k3.tiles_m = k3.tiles_n = 0; k3.splitk = d->splitk;
-            return launch_wgrad3x3(k3, st);
+            k3.nstg = k.K / 32; k3.sps = 0; k3.tiles_m = k3.tiles_n = 0; k3.splitk = d->splitk; k3.det_stride = det_stride;
+            return launch_wgrad3x3(k3, st, nsplit, dry);
         }
     }
     if (d->dtype == MG_BF16)
-        return (d->flags & 1) ? launch_wgrad<uint16_t, true>(k, st) : launch_wgrad<uint16_t, false>(k, st);
-    return launch_wgrad<float, false>(k, st);
+        return (d->flags & 1) ? launch_wgrad<uint16_t, true>(k, st, nsplit, dry) : launch_wgrad<uint16_t, false>(k, st, nsplit, dry);
+    return launch_wgrad<float, false>(k, st, nsplit, dry);
+}
+
+int check_wgrad_desc(const mg_wgrad_desc* d, const char* who)
+{
+    MG_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
+    MG_CHECK_ARG(d->x && d->dy && d->dw, "%s: null tensor pointer", who);
+    MG_CHECK_ARG(d->dtype == MG_F32 || d->dtype == MG_BF16, "%s: bad dtype %d", who, d->dtype);
+    MG_CHECK_ARG(d->ntaps >= 1 && d->ntaps <= MG_MAX_TAPS, "%s: ntaps=%d out of range", who, d->ntaps);
+    MG_CHECK_ARG(d->Cin > 0 && (d->Cin % 8) == 0 && d->Cg > 0 && (d->Cg % 8) == 0,
+                 "%s: Cin=%d / Cg=%d must be positive multiples of 8", who, d->Cin, d->Cg);
+    MG_CHECK_ARG(d->N > 0 && d->Hj > 0 && d->Wj > 0 && d->Hin > 0 && d->Win > 0, "%s: empty geometry", who);
+    MG_CHECK_ARG((long)d->N * d->Hj * d->Wj < (1L << 30), "%s: too many pixels", who);
+    return MG_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t mg_wgrad_det_workspace(const mg_wgrad_desc* d)
+{
+    if (check_wgrad_desc(d, "mg_wgrad_det_workspace") != MG_OK) return -1;
+    int S = 0;
+    if (route_wgrad(d, nullptr, d->dw, d->dbias, 0, &S, true) != MG_OK || S <= 0) return -1;
+    const long slab = (long)d->ntaps * d->Cg * d->Cin + (d->dbias ? d->Cg : 0);
+    return (int64_t)S * slab * (int64_t)sizeof(float);
+}
+
+extern "C" int mg_conv_wgrad(const mg_wgrad_desc* d, void* stream)
+{
+    const int rc = check_wgrad_desc(d, "mg_conv_wgrad");
+    if (rc != MG_OK) return rc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d->det_ws == nullptr) return route_wgrad(d, st, d->dw, d->dbias, 0, nullptr, false);
+    // deterministic split-K: every split stores its partial tile into its own slab, a finishing launch adds the slabs in split order
+    int S = 0;
+    if (route_wgrad(d, st, d->dw, d->dbias, 0, &S, true) != MG_OK || S <= 0) return mg_fail(MG_ERR_ARG, "mg_conv_wgrad: cannot size the deterministic workspace");
+    const long ndw = (long)d->ntaps * d->Cg * d->Cin, nbias = d->dbias ? d->Cg : 0, slab = ndw + nbias;
+    MG_CHECK_ARG(d->det_ws_bytes >= (int64_t)S * slab * (int64_t)sizeof(float), "mg_conv_wgrad: deterministic workspace too small (%ld splits)", (long)S);
+    float* ws = reinterpret_cast<float*>(d->det_ws);
+    int S2 = 0;
+    const int r2 = route_wgrad(d, st, ws, d->dbias ? ws + ndw : nullptr, slab, &S2, false);
+    if (r2 != MG_OK) return r2;
+    if (S2 != S) return mg_fail(MG_ERR_LAUNCH, "mg_conv_wgrad: split count changed between sizing and launch (%d vs %d)", S, S2);
+    return launch_wgrad_det_finish(ws, S, slab, d->dw, ndw, d->dbias, (int)nbias, st);
 }

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wg3K d)
         for (int mt = 0; mt < MT; ++mt) {
             const float t = bsum[mt] + __shfl_xor(bsum[mt], 32);          // the two K halves of the row
             const int co = m0 + (wm * MT + mt) * 32 + l31;
-            if (hi == 0 && co < d.Cg) atomicAdd(d.dbias + co, t);
+            if (hi == 0 && co < d.Cg) wg_accum(d.dbias, d.det_stride, split, (size_t)co, t);
         }
     }
 
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wg3K d)
         for (int r = 0; r < 16; ++r) {
             const int co = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             if (co < d.Cg)
-                atomicAdd(d.dw + ((size_t)(tap * d.Cg + co) * d.Cin + ci), acc[kx][mt][nt][r]);
+                wg_accum(d.dw, d.det_stride, split, (size_t)(tap * d.Cg + co) * d.Cin + ci, acc[kx][mt][nt][r]);
         }
     });
     if constexpr (PROBE) {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wg3K d)
 
 
 template <int MT, int NT, bool W16>
-int launch3(Wg3K& k, hipStream_t st)
+int launch3(Wg3K& k, hipStream_t st, int* nsplit, bool dry)
 {
     constexpr int TM = 64 * MT, TN = 64 * NT;
     constexpr int STAGE = 32 * TM * 2 + ((NT == 2) ? 36 : 40) * TN * 2;
@@ -311,6 +311,8 @@ int launch3(Wg3K& k, hipStream_t st)
     k.sps = (k.nstg + S - 1) / S;
     S = (k.nstg + k.sps - 1) / k.sps;
     const long nblk = base * S;
+    if (nsplit) *nsplit = S;
+    if (dry) return MG_OK;
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_wgrad: bad grid %ld", nblk);
     auto kern = wgrad3x3_kernel<MT, NT, W16>;
     static bool attr_done = false;
@@ -340,17 +342,17 @@ int wgrad3x3_set_probe(unsigned long long addr)
     return hipMemcpyToSymbol(HIP_SYMBOL(g_mg_wg3_probe_out), &p, sizeof(p)) == hipSuccess ? MG_OK : MG_ERR_ARG;
 }
 
-int launch_wgrad3x3(Wg3K& k, hipStream_t st)
+int launch_wgrad3x3(Wg3K& k, hipStream_t st, int* nsplit, bool dry)
 {
     const bool m2 = k.Cg > 64, n2 = k.Cin > 64;
     if (k.W == 16) {
-        if (m2 && n2) return launch3<2, 2, true>(k, st);
-        if (m2)       return launch3<2, 1, true>(k, st);
-        if (n2)       return launch3<1, 2, true>(k, st);
-        return launch3<1, 1, true>(k, st);
+        if (m2 && n2) return launch3<2, 2, true>(k, st, nsplit, dry);
+        if (m2)       return launch3<2, 1, true>(k, st, nsplit, dry);
+        if (n2)       return launch3<1, 2, true>(k, st, nsplit, dry);
+        return launch3<1, 1, true>(k, st, nsplit, dry);
     }
-    if (m2 && n2) return launch3<2, 2, false>(k, st);
-    if (m2)       return launch3<2, 1, false>(k, st);
-    if (n2)       return launch3<1, 2, false>(k, st);
-    return launch3<1, 1, false>(k, st);
+    if (m2 && n2) return launch3<2, 2, false>(k, st, nsplit, dry);
+    if (m2)       return launch3<2, 1, false>(k, st, nsplit, dry);
+    if (n2)       return launch3<1, 2, false>(k, st, nsplit, dry);
+    return launch3<1, 1, false>(k, st, nsplit, dry);
 }

@@ -10,8 +10,17 @@ struct Wg3K {
     int sps;                // stages per split
     int tiles_m, tiles_n;
     int splitk;             // requested split count (0 = choose)
+    long det_stride;        // deterministic mode: floats per split slab (dw / dbias then point INTO the workspace), 0 = fp32 atomics
 };
 
-int launch_wgrad3x3(Wg3K& k, hipStream_t st);   // mg_wgrad3x3.hip
+// One partial value of split `split`: an fp32 atomic into the shared dW, or (deterministic mode) a plain store into the split's own slab.
+__device__ __forceinline__ void wg_accum(float* base, long det_stride, int split, size_t idx, float v)
+{
+    if (det_stride) base[(size_t)split * det_stride + idx] = v;
+    else atomicAdd(base + idx, v);
+}
+int launch_wgrad_det_finish(const float* ws, int nsplit, long stride, float* dw, long ndw, float* dbias, int nbias, hipStream_t st);   // mg_wgrad.hip
+
+int launch_wgrad3x3(Wg3K& k, hipStream_t st, int* nsplit = nullptr, bool dry = false);   // mg_wgrad3x3.hip; dry: only report the split count
 bool wgrad_thin_applies(const Wg3K& k);           // mg_conv_thin.hip: 8-channel X, 64 / 128-channel dY
-int launch_wgrad_thin(Wg3K& k, hipStream_t st);
+int launch_wgrad_thin(Wg3K& k, hipStream_t st, int* nsplit = nullptr, bool dry = false);

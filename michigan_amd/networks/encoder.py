@@ -90,7 +90,12 @@ class ImageEncoder3(BaseNetwork):
         mean_feat = (xf * lref).sum(dim=(1, 2)) / area[:, None]                    # [N, C]
         out = mean_feat[:, None, None, :] * ltag                                     # [N, xh, xw, C]
         if self.sh != xh:
-            out = F.interpolate(out.permute(0, 3, 1, 2), size=(self.sh, self.sw), mode="bilinear").permute(0, 2, 3, 1)
+            if ops.WGRAD_DETERMINISTIC and xh == 2 * self.sh and xw == 2 * self.sw:
+                # bilinear at scale 1/2 (align_corners=False) is the mean of each 2x2 block; avg_pool2d's backward has no atomics
+                # (upsample_bilinear2d_backward accumulates with them)
+                out = F.avg_pool2d(out.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+            else:
+                out = F.interpolate(out.permute(0, 3, 1, 2), size=(self.sh, self.sw), mode="bilinear").permute(0, 2, 3, 1)
         return out.to(x.dtype).contiguous()
 
 

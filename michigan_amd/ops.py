@@ -42,6 +42,19 @@ SYNC_BN_ASYNC = os.environ.get("MG_SYNCBN_ASYNC", "0") == "1"
 # accumulates into the arena's persistent GEMM-order buffer and one batched launch per optimiser step drains it (optim.py).
 _LEGACY_WEIGHTS = os.environ.get("MG_LEGACY_WEIGHTS") == "1"      # A/B: per-layer pack / spectral norm / unpack paths (round-1 behaviour)
 GRAD_SINK = not _LEGACY_WEIGHTS
+# Deterministic weight gradients (MG_DETERMINISTIC=1 or ops.set_deterministic(True)): the wgrad kernels' split-K partial sums go to
+# per-split slabs that a finishing launch adds in a fixed order instead of fp32 atomics (mg_wgrad_desc.det_ws); costs one pass over
+# splits x |dW| per convolution.  Everything else on the path is deterministic already (two-stage reductions, fixed-order split-K forward).
+WGRAD_DETERMINISTIC = os.environ.get("MG_DETERMINISTIC") == "1"
+
+
+def set_deterministic(flag: bool = True) -> bool:
+    """Bit-reproducible backward passes (see WGRAD_DETERMINISTIC); returns the previous setting."""
+    global WGRAD_DETERMINISTIC
+    prev, WGRAD_DETERMINISTIC = WGRAD_DETERMINISTIC, bool(flag)
+    return prev
+
+
 STATS_FROM_UPSAMPLE_SOURCE = True     # batch statistics of a 2x-upsampled tensor from its quarter-size source (A/B: tools/ab_pyflag.py)
 
 
@@ -398,6 +411,13 @@ def _wgrad_launch(x, dy, taps, stride, want_bias, out=None):
     d.flags = 1 if (WGRAD_USE_TR and x.dtype == torch.bfloat16) else 0
     _set_taps(d, taps)
     assert dy.dtype == x.dtype
+    if WGRAD_DETERMINISTIC:
+        # split-K partials into per-split slabs + an ordered sum instead of fp32 atomics: bit-reproducible weight gradients
+        nbytes = int(C.backend().mg_wgrad_det_workspace(ctypes.byref(d)))
+        if nbytes < 0:
+            raise RuntimeError("mg_wgrad_det_workspace failed")
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+        d.det_ws, d.det_ws_bytes = ws.data_ptr(), nbytes
     C.backend().mg_conv_wgrad(d, _stream(x))
     return (dw, dbias) if want_bias else dw
 

@@ -84,6 +84,9 @@ class EmulatorBackend:
     def mg_abi_version(self):
         return 3
 
+    def mg_wgrad_det_workspace(self, d):
+        return 16            # the emulator's weight gradient is a deterministic float64 sum: nothing to size
+
     def mg_sizeof_desc(self, which):
         from michigan_amd import _cabi
         return ctypes.sizeof((_cabi.ConvDesc, _cabi.WgradDesc, _cabi.GradSlot, _cabi.PackJob, _cabi.SnLayer, _cabi.NormApply2Desc, _cabi.PyramidDesc)[which])
