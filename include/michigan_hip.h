@@ -435,6 +435,12 @@ int mg_pixel_affine(const void* x, const float* a, const float* bias, const floa
 int mg_bg_compose(const float* image, const float* noise, const float* hair, int64_t hair_nstride, int32_t dtype,
                   int32_t N, int32_t H, int32_t W, int32_t k, int32_t mode, void* inp, float* back, void* stream);
 
+/* ImageEncoder3's tail (encoder.py:211-220) and its adjoint: out[n, q, c] = w_out[n, q] * sum_p(x[n, p, c] * w_in[n, p]) / max(sum_p w_norm[n, p], 1),
+ * x [N, P, C] in `dtype` (C % 4 == 0), the three weights fp32 [N, P], out fp32 [N, P, C].  Forward: w_in = w_norm = reference hair mask,
+ * w_out = target hair mask; backward (x = the incoming gradient): w_in = target mask, w_out = w_norm = reference mask. */
+int mg_masked_mean_fill(const void* x, const float* w_in, const float* w_out, const float* w_norm, int32_t dtype, int32_t N, int32_t P,
+                        int32_t C, float* out, void* stream);
+
 /* Tail of the Gabor orientation loss behind mg_gabor_argmax_fwd (loss.py:352-385).  conf_raw fp32 [N,HW] (max clamped response),
  * idx u8 [N,HW] (winning filter), label: label_ch == 2: planes (sin 2t, cos 2t) of sample n at label + n * label_nstride (+ HW for
  * the second); label_ch == 1: the loader's 0..255 angle map.  confidence = (tanh(conf_raw) + 1) / 2, fake = (sin 2a, cos 2a) *

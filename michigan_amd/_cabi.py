@@ -130,6 +130,7 @@ _PROTOS = {
     "mg_pconv_mask": ([_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp], _i32),
     "mg_pixel_affine": ([_vp, _vp, _vp, _vp, _i32, _i64, _i32, _vp, _vp], _i32),
     "mg_bg_compose": ([_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp], _i32),
+    "mg_masked_mean_fill": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp], _i32),
     "mg_orient_loss_fwd": ([_vp, _vp, _vp, _i32, _i64, _vp, _i64, _i32, _i64, _vp, _vp, _vp], _i32),
     "mg_orient_loss_bwd": ([_vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
     "mg_gabor_argmax_fwd": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),

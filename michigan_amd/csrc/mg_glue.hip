@@ -245,6 +245,53 @@ __global__ void orient_loss_bwd_kernel(const float* __restrict__ conf_raw, const
     }
 }
 
+// ---- masked mean over a region, broadcast into another region (ImageEncoder3's tail, encoder.py:211-220) -----------------------------
+// out[n, q, c] = w_out[n, q] * (sum_p x[n, p, c] * w_in[n, p]) / max(sum_p w_norm[n, p], 1): the mean feature of the reference hair region
+// written over the target hair region (forward: w_in = w_norm = lref, w_out = ltag) and its adjoint (backward: w_in = ltag, w_out = w_norm =
+// lref).  A block owns one sample and 16 channel quads; 16 thread rows split the pixels.  P <= a few thousand (the 16 x 16 latent).
+template <typename T>
+__global__ __launch_bounds__(256) void masked_mean_fill_kernel(const T* __restrict__ x, const float* __restrict__ w_in, const float* __restrict__ w_out,
+                                                               const float* __restrict__ w_norm, int P, int C, float* __restrict__ out)
+{
+    __shared__ float red[16][16][4];
+    __shared__ float nrm[16];
+    const int n = blockIdx.y, tq = threadIdx.x & 15, tp = threadIdx.x >> 4;
+    const int c = (blockIdx.x * 16 + tq) * 4;
+    const bool cv = c < C;
+    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+    float a = 0.f;
+    for (int p = tp; p < P; p += 16) {
+        const float wi = w_in[(size_t)n * P + p];
+        if (tq == 0) a += w_norm[(size_t)n * P + p];
+        if (cv && wi != 0.f) {
+            const f32x4_t v = ET<T>::load4(x + ((size_t)n * P + p) * C + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += v[j] * wi;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[tp][tq][j] = s[j];
+    if (tq == 0) nrm[tp] = a;
+    __syncthreads();
+    float area = 0.f;
+    for (int r = 0; r < 16; ++r) area += nrm[r];
+    area = fmaxf(area, 1.f);
+    f32x4_t m = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] += red[r][tq][j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] /= area;
+    if (!cv) return;
+    for (int q = tp; q < P; q += 16) {
+        const float wo = w_out[(size_t)n * P + q];
+        f32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = m[j] * wo;
+        *reinterpret_cast<f32x4_t*>(out + ((size_t)n * P + q) * C + c) = o;
+    }
+}
+
 inline int ew_grid(int64_t n, int thr = 256, int cap = 4096) { const int64_t g = (n + thr - 1) / thr; return (int)(g > cap ? cap : (g < 1 ? 1 : g)); }
 
 }  // namespace
@@ -331,5 +378,18 @@ extern "C" int mg_orient_loss_bwd(const float* conf_raw, const uint8_t* idx, con
     hipLaunchKernelGGL(orient_loss_bwd_kernel, dim3(ew_grid((int64_t)N * HW)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        conf_raw, idx, label, label_ch, label_nstride, hair, hair_nstride, g_orient, g_conf, fwd_out, N, HW, dconf);
     MG_CHECK_LAUNCH("mg_orient_loss_bwd");
+    return MG_OK;
+}
+
+extern "C" int mg_masked_mean_fill(const void* x, const float* w_in, const float* w_out, const float* w_norm, int32_t dtype, int32_t N,
+                                   int32_t P, int32_t C, float* out, void* stream)
+{
+    MG_CHECK_ARG(x && w_in && w_out && w_norm && out, "mg_masked_mean_fill: null pointer");
+    MG_CHECK_ARG((dtype == MG_F32 || dtype == MG_BF16) && N > 0 && P > 0 && C > 0 && (C & 3) == 0, "mg_masked_mean_fill: bad geometry");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((C / 4 + 15) / 16, N);
+    if (dtype == MG_BF16) hipLaunchKernelGGL(masked_mean_fill_kernel<uint16_t>, grid, dim3(256), 0, st, (const uint16_t*)x, w_in, w_out, w_norm, P, C, out);
+    else hipLaunchKernelGGL(masked_mean_fill_kernel<float>, grid, dim3(256), 0, st, (const float*)x, w_in, w_out, w_norm, P, C, out);
+    MG_CHECK_LAUNCH("mg_masked_mean_fill");
     return MG_OK;
 }

@@ -152,6 +152,14 @@ class Pix2PixModel(nn.Module):
         d["orient"] = orient.detach()
         return d
 
+    def drop_input_caches(self):
+        """Forget what was derived from the previous batch's inputs (see Pix2PixTrainer.run_generator_one_step)."""
+        for mod in (self.netG, getattr(self.netG, "fc", None), getattr(self, "criterionGAN", None)):
+            d = getattr(mod, "__dict__", None)
+            if d is not None:
+                for k in ("_mg_input_cache", "_mg_mask_chain", "_mg_wide_edge", "_mg_label_src"):
+                    d.pop(k, None)
+
     # -- networks -------------------------------------------------------------------
     def zeros_padding(self, t):
         """pix2pix_model.py:495-502: th/2 zeros on every side (the padded canvas the networks see under --add_feat_zeros)."""
@@ -340,9 +348,10 @@ class Pix2PixTrainer:
             p.requires_grad_(flag)
 
     def run_generator_one_step(self, data):
-        # a new step: the generator's input-only pyramids are rebuilt (they are re-used only by this step's second generator pass,
-        # never across steps -- a benchmark that feeds the same synthetic batch every step must not get them for free)
-        getattr(self.pix2pix_model.netG, "__dict__", {}).pop("_mg_input_cache", None)
+        # a new step: everything derived from the inputs alone (conditioning / mask pyramids, the partial-conv mask chain, the wide-edge
+        # weight masks) is rebuilt -- it is re-used only within a step (second generator pass, D's fake / real terms), never across
+        # steps: a benchmark that feeds the same synthetic batch every step must not get it for free
+        self.pix2pix_model.drop_input_caches()
         self.optimizer_G.zero_grad()
         self._set_d_requires_grad(False)
         try:

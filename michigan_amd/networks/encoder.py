@@ -83,12 +83,18 @@ class ImageEncoder3(BaseNetwork):
             else:
                 x = F.leaky_relu(x, 0.2)
         n, xh, xw, c = x.shape
-        lref = F.interpolate(label_ref0.float(), size=(xh, xw), mode="nearest").permute(0, 2, 3, 1)
-        ltag = F.interpolate(label_tag0.float(), size=(xh, xw), mode="nearest").permute(0, 2, 3, 1)
-        xf = x.float()
-        area = lref.sum(dim=(1, 2, 3)).clamp_min(1.0)
-        mean_feat = (xf * lref).sum(dim=(1, 2)) / area[:, None]                    # [N, C]
-        out = mean_feat[:, None, None, :] * ltag                                     # [N, xh, xw, C]
+        if c % 4 == 0 and label_ref0.dtype == torch.float32 and label_tag0.dtype == torch.float32 and label_ref0.shape[1] == 1:
+            # each mask at the latent resolution in one launch, then mean over the reference region -> target region in one launch
+            lref = ops.nearest_pyramid([label_ref0.detach()[:, 0]], [(xh, xw)], 1, torch.float32)[0]
+            ltag = ops.nearest_pyramid([label_tag0.detach()[:, 0]], [(xh, xw)], 1, torch.float32)[0]
+            out = ops.masked_mean_fill(x, lref, ltag)                                    # fp32 [N, xh, xw, C]
+        else:
+            lref = F.interpolate(label_ref0.float(), size=(xh, xw), mode="nearest").permute(0, 2, 3, 1)
+            ltag = F.interpolate(label_tag0.float(), size=(xh, xw), mode="nearest").permute(0, 2, 3, 1)
+            xf = x.float()
+            area = lref.sum(dim=(1, 2, 3)).clamp_min(1.0)
+            mean_feat = (xf * lref).sum(dim=(1, 2)) / area[:, None]                    # [N, C]
+            out = mean_feat[:, None, None, :] * ltag                                     # [N, xh, xw, C]
         if self.sh != xh:
             if ops.WGRAD_DETERMINISTIC and xh == 2 * self.sh and xw == 2 * self.sw:
                 # bilinear at scale 1/2 (align_corners=False) is the mean of each 2x2 block; avg_pool2d's backward has no atomics

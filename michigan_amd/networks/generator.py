@@ -66,7 +66,12 @@ class SPADEBGenerator(BaseNetwork):
         opt, dt = self.opt, self.compute_dtype
         input_tag = input_tag.float()
         hair = input_tag[:, 1:2]
-        x = self.fc(ops.pad_channels(ops.to_nhwc(image_ref, dt), 8), input[:, 1:2], hair)
+        if image_ref.dtype == torch.float32 and image_ref.shape[1] <= 8 and not image_ref.requires_grad:
+            ref8 = torch.empty((image_ref.shape[0], image_ref.shape[2], image_ref.shape[3], 8), dtype=dt, device=image_ref.device)
+            ref8 = ops.assemble_nhwc8(ref8, 0, image_ref)              # NCHW fp32 -> NHWC8 in the activation dtype: one launch (was permute-copy + pad)
+        else:
+            ref8 = ops.pad_channels(ops.to_nhwc(image_ref, dt), 8)
+        x = self.fc(ref8, input[:, 1:2], hair)
 
         # The conditioning pyramid and the hair-mask pyramid depend on the inputs only.  A training step runs the generator twice on
         # the same batch (generator step, then under no_grad for the discriminator step): the second pass re-uses them (~50 small

@@ -1457,6 +1457,39 @@ def bg_compose(image: Optional[torch.Tensor], noise: Optional[torch.Tensor], hai
     return inp, back
 
 
+class _MaskedMeanFillFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lref, ltag):
+        x = _nhwc(x)
+        n, h, w, c = x.shape
+        out = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+        C.backend().mg_masked_mean_fill(_p(x), _p(lref), _p(ltag), _p(lref), _dt(x), n, h * w, c, _p(out), _stream(x))
+        ctx.save_for_backward(lref, ltag)
+        ctx.xdtype = x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lref, ltag = ctx.saved_tensors
+        g = g.contiguous()
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        n, h, w, c = g.shape
+        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=g.device)
+        C.backend().mg_masked_mean_fill(_p(g), _p(ltag), _p(lref), _p(lref), _dt(g), n, h * w, c, _p(dx), _stream(g))
+        return (dx if ctx.xdtype == torch.float32 else dx.to(ctx.xdtype)), None, None
+
+
+def masked_mean_fill(x: torch.Tensor, lref: torch.Tensor, ltag: torch.Tensor) -> torch.Tensor:
+    """ImageEncoder3's tail (encoder.py:211-220): per sample, the mean of x over the region lref (area clamped to >= 1) written over the
+    region ltag: fp32 [N, H, W, C].  x NHWC; lref / ltag fp32 with one value per pixel."""
+    lref = lref.detach().float().reshape(x.shape[0], -1).contiguous()
+    ltag = ltag.detach().float().reshape(x.shape[0], -1).contiguous()
+    if x.shape[-1] % 4 or lref.shape[1] * x.shape[-1] != x[0].numel():
+        raise ValueError("masked_mean_fill: one weight per pixel and C % 4 == 0 expected")
+    return _MaskedMeanFillFn.apply(x, lref, ltag)
+
+
 class _OrientLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, conf_raw, idx, label, hair):

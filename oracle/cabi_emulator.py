@@ -748,6 +748,14 @@ class EmulatorBackend:
         _view(back, (N, H, W), torch.float32)[:] = bk[:, 0]
         return 0
 
+    def mg_masked_mean_fill(self, x, w_in, w_out, w_norm, dtype, N, P, C, out, stream=None):
+        xv = _view(x, (N, P, C), _TD[dtype]).double()
+        wi, wo, wn = (_view(t, (N, P, 1), torch.float32).double() for t in (w_in, w_out, w_norm))
+        area = wn.sum(dim=(1, 2)).clamp_min(1.0)
+        mean = (xv * wi).sum(dim=1) / area[:, None]                                   # encoder.py:216-219
+        _view(out, (N, P, C), torch.float32)[:] = (mean[:, None, :] * wo).float()
+        return 0
+
     def _orient_terms(self, conf_raw, idx, label, label_ch, label_nstride, hair, hair_nstride, N, HW):
         cr = _view(conf_raw, (N, HW), torch.float32).double()
         ix = _view(idx, (N, HW), torch.uint8).double()

@@ -917,6 +917,18 @@ def test_glue_kernels_match_contract(dt):
         (hip, _), (ref, _) = _both(bgc, (image, noise, m2))
         assert torch.equal(hip[1].cpu(), ref[1]), (k, mode)
         _close(f"bg_compose {dt} k={k}", hip[0], ref[0], TOL[dt])
+    # masked mean over the reference region written over the target region (ImageEncoder3's tail), forward and adjoint
+    feat = torch.randn(3, 16, 12, 72, generator=g).to(td).requires_grad_()
+    lref, ltag = (torch.rand(3, 16, 12, 1, generator=g) > 0.6).float(), (torch.rand(3, 16, 12, 1, generator=g) > 0.4).float()
+    lref[2] = 0                                                            # an empty reference region: the area clamps to 1
+
+    def mmf(feat, lref, ltag):
+        out = ops.masked_mean_fill(feat, lref, ltag)
+        gx, = torch.autograd.grad((out * out).sum(), feat)
+        return out, gx
+    (hip, _), (ref, _) = _both(mmf, (feat, lref, ltag))
+    _close(f"masked_mean_fill {dt}", hip[0], ref[0], 1e-5)
+    _close(f"masked_mean_fill {dt} adjoint", hip[1], ref[1], TOL[dt])
     # orientation-loss tail: both label forms, gradient of either output
     conf_raw = (torch.randn(2, 48, 40, generator=g) * 1.5).requires_grad_()
     idx = torch.randint(0, 32, (2, 48, 40), generator=g, dtype=torch.uint8)

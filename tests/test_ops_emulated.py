@@ -223,6 +223,16 @@ def test_glue_contracts_match_the_eager_chains_they_replace(emulator_backend):
     seg = torch.randn(2, 4, 40, 44, generator=g)
     for t, (h, w_) in zip(ops.nearest_pyramid(ops.planes_of(seg), [(5, 5), (10, 11), (20, 22)], 8, torch.float32), [(5, 5), (10, 11), (20, 22)]):
         assert torch.equal(t[..., :4].permute(0, 3, 1, 2), F.interpolate(seg, size=(h, w_), mode="nearest")) and float(t[..., 4:].abs().max()) == 0
+    # ImageEncoder3's tail (encoder.py:211-220) and its gradient vs autograd through the eager formula
+    feat = torch.randn(2, 8, 6, 12, generator=g).requires_grad_()
+    lr_, lt_ = (torch.rand(2, 8, 6, 1, generator=g) > 0.5).float(), (torch.rand(2, 8, 6, 1, generator=g) > 0.5).float()
+    area = lr_.sum(dim=(1, 2, 3)).clamp_min(1.0)
+    want_f = ((feat * lr_).sum(dim=(1, 2)) / area[:, None])[:, None, None, :] * lt_
+    gwf, = torch.autograd.grad((want_f ** 2).sum(), feat)
+    f2 = feat.detach().clone().requires_grad_()
+    got_f = ops.masked_mean_fill(f2, lr_, lt_)
+    ggf, = torch.autograd.grad((got_f ** 2).sum(), f2)
+    assert (got_f - want_f).abs().max() < 1e-6 and (ggf - gwf).abs().max() < 1e-5
     # orientation-loss tail and its gradient vs autograd through the reference's formula
     conf_raw = torch.randn(2, 16, 12, generator=g, dtype=torch.float64).float().requires_grad_()
     idx = torch.randint(0, 32, (2, 16, 12), generator=g, dtype=torch.uint8)

@@ -75,7 +75,7 @@ class CountingBackend:
 
 def main():
     import parity_utils as PU  # noqa: F401
-    from michigan_amd.model import Pix2PixTrainer, default_options
+    from michigan_amd.model import Pix2PixTrainer, _total, default_options
     from michigan_amd.synth import synth_batch
     torch.set_num_threads(4)
     census = Census()
@@ -87,7 +87,7 @@ def main():
     m = tr.pix2pix_model
 
     def g_step(count):
-        getattr(m.netG, "__dict__", {}).pop("_mg_input_cache", None)
+        m.drop_input_caches()
         ph = (lambda p: setattr(census, "phase", p)) if count else (lambda p: None)
         ph("G.zero_grad"); tr.optimizer_G.zero_grad(); tr._set_d_requires_grad(False)
         ph("G.preprocess"); d = m.preprocess_input(data); d = m._maybe_inpaint(d); pending = m._ref_is_tag_async(d)
@@ -99,7 +99,7 @@ def main():
         ph("G.loss_feat"); lf = m.criterionGANFeat(pf, pr, label)
         ph("G.loss_vgg"); lv = m.criterionVGG(fake, d["image_tag"], label) * opt.lambda_vgg
         ph("G.loss_orient"); lo = m.criterionOrient(fake, d["orient"], d["input_tag"])[0] * opt.lambda_orient
-        ph("G.loss_sum"); loss = sum({"a": lg, "b": lf, "c": lv, "d": lo}.values()).mean()
+        ph("G.loss_sum"); loss = _total({"a": lg, "b": lf, "c": lv, "d": lo})
         ph("G.backward"); loss.backward(); tr._set_d_requires_grad(True)
         ph("G.optimizer"); tr.optimizer_G.step()
 
@@ -114,7 +114,7 @@ def main():
         ph("D.discriminate"); pf, pr = m.discriminate(d, fake)
         label = d["input_tag"][:, 1:2]
         ph("D.loss"); l1 = m.criterionGAN(pf, False, for_discriminator=True, label=label); l2 = m.criterionGAN(pr, True, for_discriminator=True, label=label)
-        loss = sum({"a": l1, "b": l2}.values()).mean()
+        loss = _total({"a": l1, "b": l2})
         ph("D.backward"); loss.backward()
         ph("D.optimizer"); tr.optimizer_D.step()
 
