@@ -253,35 +253,36 @@ template <typename T>
 __global__ __launch_bounds__(256) void masked_mean_fill_kernel(const T* __restrict__ x, const float* __restrict__ w_in, const float* __restrict__ w_out,
                                                                const float* __restrict__ w_norm, int P, int C, float* __restrict__ out)
 {
-    __shared__ float red[16][16][4];
-    __shared__ float nrm[16];
+    __shared__ double red[16][16][4];
+    __shared__ double nrm[16];
     const int n = blockIdx.y, tq = threadIdx.x & 15, tp = threadIdx.x >> 4;
     const int c = (blockIdx.x * 16 + tq) * 4;
     const bool cv = c < C;
-    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-    float a = 0.f;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};                       // fp64 sums: a few thousand elements per block, free; the latent statistics are ill-conditioned enough
+    double a = 0.0;
     for (int p = tp; p < P; p += 16) {
         const float wi = w_in[(size_t)n * P + p];
-        if (tq == 0) a += w_norm[(size_t)n * P + p];
+        if (tq == 0) a += (double)w_norm[(size_t)n * P + p];
         if (cv && wi != 0.f) {
             const f32x4_t v = ET<T>::load4(x + ((size_t)n * P + p) * C + c);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s[j] += v[j] * wi;
+            for (int j = 0; j < 4; ++j) s[j] += (double)v[j] * (double)wi;
         }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[tp][tq][j] = s[j];
     if (tq == 0) nrm[tp] = a;
     __syncthreads();
-    float area = 0.f;
+    double area = 0.0;
     for (int r = 0; r < 16; ++r) area += nrm[r];
-    area = fmaxf(area, 1.f);
-    f32x4_t m = {0.f, 0.f, 0.f, 0.f};
-    for (int r = 0; r < 16; ++r)
+    area = area > 1.0 ? area : 1.0;
+    f32x4_t m;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m[j] += red[r][tq][j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) m[j] /= area;
+    for (int j = 0; j < 4; ++j) {
+        double t = 0.0;
+        for (int r = 0; r < 16; ++r) t += red[r][tq][j];
+        m[j] = (float)(t / area);
+    }
     if (!cv) return;
     for (int q = tp; q < P; q += 16) {
         const float wo = w_out[(size_t)n * P + q];
