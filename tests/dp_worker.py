@@ -12,7 +12,8 @@ mode:
   repo     michigan_amd.model.Pix2PixTrainer (FlatAdam: in-place reduction of the GEMM-order gradient arena)
   reflike  the reference trainer's flow (pix2pix_trainer.py:17-77) over michigan_amd.model.Pix2PixModel: DataParallelWithCallback wrap,
            then torch.optim.Adam from create_optimizers -> parallel.GradAverager; D keeps requires_grad in the generator step
-env: MG_TEST_BACKEND = nccl (default with a GPU) | gloo (CPU: contract emulator backend).
+env: MG_TEST_BACKEND = nccl (default with a GPU) | gloo (CPU: contract emulator backend) | gloo_hip (the real HIP kernels with every rank on
+     cuda:0 and the collectives through gloo: a 2-rank run of the device path on a ONE-GPU box).
 """
 import os
 import random
@@ -79,6 +80,12 @@ def main(mode):
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
         dist.init_process_group("nccl", device_id=device)
+    elif backend == "gloo_hip":
+        local = 0
+        torch.cuda.set_device(0)
+        device = torch.device("cuda", 0)
+        assert _cabi.backend().name == "hip"
+        dist.init_process_group("gloo")
     else:
         from oracle.cabi_emulator import EmulatorBackend
         _cabi.set_backend(EmulatorBackend())

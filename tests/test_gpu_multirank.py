@@ -6,6 +6,7 @@
     tests/golden/trainer_A.npz; replicas bitwise identical; sync-BN statistics and gradient buckets on two communicators.
     Both consumers: this repo's trainer (FlatAdam arena reduction) and the reference trainer's flow (DataParallelWithCallback wrap +
     torch.optim.Adam + parallel.GradAverager = what `dropin.install()` gives the reference's own pix2pix_trainer.py).
+  * two ranks SHARING the one GPU, collectives over gloo, real kernels (both consumers): runs on every box;
   * one rank with every collective forced (MG_DP_FORCE=1) for the reference-flow consumer: the RCCL call pattern of the drop-in's
     gradient averaging (gradients adopted into flat buckets from post-accumulate hooks, asynchronous all-reduce on the process
     group's stream, pre-step wait + scale) on the real kernels of a one-GPU box.  (The FlatAdam consumer's one-rank run is
@@ -43,6 +44,16 @@ def test_two_rank_rccl_trainer_matches_reference_golden(hip_backend, mode):
 def test_two_rank_rccl_one_communicator_ab(hip_backend):
     """MG_DP_ONE_GROUP=1 (sync-BN statistics and gradient buckets on ONE communicator, the round-2 layout) stays correct: the A/B switch."""
     _launch("repo", 2, 29633, {"MG_DP_ONE_GROUP": "1"})
+
+
+@pytest.mark.parametrize("mode", ["repo", "reflike"])
+def test_two_ranks_sharing_one_gpu_over_gloo_match_reference_golden(hip_backend, mode):
+    """World size 2 on the REAL kernels of a one-GPU box: both ranks drive cuda:0, the collectives travel through gloo (host memory).
+    Everything but the transport is the multi-GPU path -- cross-rank batch statistics from the HIP reductions, gradient buckets of the
+    GEMM-order arena (repo) / GradAverager buckets adopted from autograd hooks (reflike), two process groups, the parameter broadcast
+    from different per-rank initialisations -- against the reference trainer's goldens, replicas bitwise identical."""
+    out = _launch(mode, 2, 29635 if mode == "repo" else 29636, {"MG_TEST_BACKEND": "gloo_hip"})
+    assert "world=2" in out
 
 
 def test_one_rank_forced_rccl_reference_flow_matches_golden(hip_backend):
