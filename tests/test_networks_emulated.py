@@ -103,3 +103,44 @@ def test_split_discriminator_pass_equals_stacked_pass(emulator_backend):
     assert a[3].keys() == b[3].keys() and len(a[3]) > 0
     for k in a[3]:
         assert torch.allclose(a[3][k], b[3][k], rtol=1e-6, atol=1e-7), k
+
+
+def test_generator_under_inference_mode_and_copy_pickle_after_forward(emulator_backend, tmp_path):
+    """the generator's input cache read `t._version` of inference tensors (which have none) and left weak references /
+    ctypes tables in module.__dict__ that broke copy.deepcopy / torch.save(module) after the first forward."""
+    import copy
+    import random
+    import parity_utils as PU
+    from michigan_amd import networks
+    from michigan_amd.synth import synth_batch, synth_state_dict
+    opt = PU.small_opt(ngf=8, crop_size=64)
+    G = networks.SPADEBGenerator(opt).train()
+    G.load_state_dict(synth_state_dict(G.state_dict(), seed=3, gain=1.0))
+    b = synth_batch(2, 64, seed=5)
+    call = lambda net, bb: net(bb["input_ref"], orient_mask=bb["orient"], image_ref=bb["image_ref"], input_tag=bb["input_tag"],
+                               noise=bb["noise"], image_tag=bb["image_tag"])
+    random.seed(1)
+    with torch.no_grad():
+        want = call(G, b)
+    G.load_state_dict(synth_state_dict(G.state_dict(), seed=3, gain=1.0))          # running statistics / u, v back to the start
+    random.seed(1)
+    with torch.inference_mode():
+        bi = {k: v.clone() for k, v in b.items()}                                   # inference tensors: no version counter
+        got = call(G, bi)
+    assert (want - got).abs().max().item() < 1e-5          # (first call: per-layer weight paths, second: batched -- last-bit differences)
+    G2 = copy.deepcopy(G)                                                           # transient per-process caches are not copied
+    assert "_mg_input_cache" not in G2.__dict__ and "_mg_spectral_plan" not in G2.__dict__
+    torch.save(G, tmp_path / "g.pt")
+    G3 = torch.load(tmp_path / "g.pt", weights_only=False)
+    for a, c in zip(G.state_dict().values(), G3.state_dict().values()):
+        assert torch.equal(a, c)
+    random.seed(2)
+    with torch.no_grad():
+        o1 = call(G, b)
+    for net in (G2, G3):
+        net.load_state_dict(G.state_dict())
+    # (G advanced its running statistics / u, v in the call above; the copies start from that state and must still run)
+    random.seed(2)
+    with torch.no_grad():
+        o2 = call(G2, b)
+    assert o2.shape == o1.shape and torch.isfinite(o2).all()
