@@ -443,7 +443,30 @@ class FlatAdam:
         self.step_count = steps.pop() if steps else 0
 
     # ---- update -------------------------------------------------------------------------
+    def _adopt_detached_grads(self):
+        """A gradient that autograd put somewhere else (after `module.zero_grad()` / `p.grad = None` the next backward allocates a fresh
+        tensor instead of accumulating into the arena view) would be invisible to the arena-wide Adam kernel: fold it into its slice of the
+        gradient arena and re-attach the view.  One pointer comparison per parameter on the host."""
+        if self.dp and (self._launched_any or self._work):
+            return                                   # buckets in flight: sync_grads raises / handles it
+        for p in self._order:
+            g = p.grad
+            if g is None:
+                continue
+            a, b = self._span_of[id(p)]
+            if g.data_ptr() != self.flat_grad.data_ptr() + 4 * a or g.dtype != torch.float32:
+                if self.dp and not self.sink and self.overlap:
+                    raise RuntimeError("FlatAdam (data parallel): a parameter's .grad was detached from the gradient arena (zero_grad(set_to_none) on the "
+                                       "module?); use optimizer.zero_grad()")
+                # the slice is stale (whoever detached .grad bypassed zero_grad(); nothing was accumulated into it since: the gradient
+                # sink only takes parameters whose .grad IS the arena view): the detached tensor is this step's whole gradient
+                view = self.flat_grad[a:b].view(p.shape)
+                with torch.no_grad():
+                    view.copy_(g)
+                p.grad = view
+
     def step(self):
+        self._adopt_detached_grads()
         self.sync_grads()
         self.step_count += 1
         lr = self.param_groups[0]["lr"]

@@ -251,3 +251,29 @@ def test_glue_contracts_match_the_eager_chains_they_replace(emulator_backend):
     gg, = torch.autograd.grad(lo * 2 + lc * 0.5, cr2)
     assert abs(float(lo) - float(want_o)) < 1e-6 and abs(float(lc) - float(want_c)) < 1e-6
     assert (gg - gw).abs().max() < 1e-6 * max(1.0, float(gw.abs().max()))
+
+
+def test_flatadam_adopts_gradients_detached_from_its_arena(emulator_backend):
+    """`module.zero_grad()` (set_to_none) detaches p.grad from the flat gradient arena; the next backward then leaves the
+    gradient in a fresh tensor the arena-wide Adam kernel never sees.  step() folds such gradients back in."""
+    from michigan_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(8, 4)
+    ref = torch.nn.Linear(8, 4)
+    ref.load_state_dict(lin.state_dict())
+    opt = FlatAdam(lin.parameters(), lr=1e-2, betas=(0.0, 0.9))
+    topt = torch.optim.Adam(ref.parameters(), lr=1e-2, betas=(0.0, 0.9))
+    x = torch.randn(5, 8)
+    for it in range(3):
+        if it == 1:
+            lin.zero_grad(set_to_none=True)              # NOT the optimiser's zero_grad: gradients leave the arena
+        else:
+            opt.zero_grad()
+        topt.zero_grad()
+        lin(x).square().sum().backward()
+        ref(x).square().sum().backward()
+        opt.step()
+        topt.step()
+        for a, b in zip(lin.parameters(), ref.parameters()):
+            assert (a - b).abs().max().item() < 1e-6, it
+            assert a.grad.data_ptr() == opt.flat_grad[opt._span_of[id(a)][0]:].data_ptr()
