@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1, help="0 register-staged, 1 LDS-DMA ring")
     ap.add_argument("--bigtiles", type=int, default=1)
     ap.add_argument("--halo", type=int, default=1)
+    ap.add_argument("--data", default="randn", choices=["randn", "zeros", "relu"],
+                    help="operand values: randn (default), zeros (the part's DVFS gives back clock when nothing toggles), relu (half zeros, like the SPADE actv map)")
+    ap.add_argument("--iters", type=int, default=5)
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     from michigan_amd import _cabi
@@ -63,15 +66,19 @@ def main():
         w = torch.randn(cout, cin, k, k, device="cuda") * 0.05
         ho = (H + 2 * p - k) // s + 1
         dy = torch.randn(a.n, ho, ho, cout, device="cuda").to(dt)
+        if a.data == "zeros":
+            x.zero_(); w.zero_(); dy.zero_()
+        elif a.data == "relu":
+            x.clamp_(min=0); dy.clamp_(min=0)
         gf = 2.0 * a.n * ho * ho * cout * cin * k * k / 1e9
         cx = x.shape[-1]
         wp = ops.pack_weight(w, None, dt, (cout + 127) // 128 * 128, cx, 0)
         wt = ops.pack_weight(w, None, dt, (cx + 127) // 128 * 128, cout, 1)
         out = torch.empty(a.n, ho, ho, cout, device="cuda", dtype=dt)
         taps = ops.fwd_taps(k, k, p)
-        t_f = timeit(lambda: ops._launch_conv(x, wp, out, None, taps, Hj=ho, Wj=ho, isy=s, isx=s, cout=cout, cout_gemm=cout))
-        t_d = timeit(lambda: ops.conv_dgrad(dy, wt, k, k, s, p, (H, H), cx))
-        t_w = timeit(lambda: ops.conv_wgrad(x, dy, k, k, s, p))
+        t_f = timeit(lambda: ops._launch_conv(x, wp, out, None, taps, Hj=ho, Wj=ho, isy=s, isx=s, cout=cout, cout_gemm=cout), a.iters)
+        t_d = timeit(lambda: ops.conv_dgrad(dy, wt, k, k, s, p, (H, H), cx), a.iters)
+        t_w = timeit(lambda: ops.conv_wgrad(x, dy, k, k, s, p), a.iters)
         print(f"{name:28s} {gf:8.1f} | {t_f:8.3f} {gf / t_f:7.1f} | {t_d:8.3f} {gf / t_d:7.1f} | {t_w:8.3f} {gf / t_w:7.1f}", flush=True)
 
 
