@@ -276,6 +276,13 @@ def main():
             ips, threads, what = bounded_baseline(a.size)
             out["cpu_baseline"] = {"value": round(ips, 4), "unit": "images/s", "cores": threads, "kind": "port",
                                    "sample": "torch-CPU restatement of the reference (oracle/): " + what}
+            rvp = os.path.join(ROOT, "profiles", "r03_cpu_reference_vs_port.json")
+            if os.path.exists(rvp):                            # the real reference cannot travel to this box: how the port relates to it where both run
+                with open(rvp) as fh:
+                    rj = json.load(fh)
+                out["cpu_baseline"]["port_vs_real_reference"] = {
+                    "port_over_reference_speed": rj["port_over_reference_speed"], "reference_images_per_s": rj["reference"]["images_per_s"],
+                    "port_images_per_s": rj["port"]["images_per_s"], "where": rj["what"], "source": "profiles/r03_cpu_reference_vs_port.json"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
