@@ -236,9 +236,9 @@ def main():
                 all_conv["traffic_gb_per_step"] = round(tj["conv"]["hbm_bytes_per_step"] / 1e9, 2)
                 roof["traffic_source"] = ("profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s"
                                           % (os.path.basename(tfile), tj.get("commit")))
-                from michigan_amd.build import _fingerprint
+                from michigan_amd.build import source_hash
                 # the PMC passes are separate runs: say whether they were taken on THESE kernel sources (hash of csrc/ + include/ + flags)
-                roof["traffic_same_kernel_sources"] = tj.get("kernel_sources") == _fingerprint()[:16]
+                roof["traffic_same_kernel_sources"] = tj.get("kernel_sources") == source_hash()
     if world > 1:
         dist.barrier()
 

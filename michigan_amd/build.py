@@ -51,6 +51,20 @@ def _fingerprint(src: str = "") -> str:
     return h.hexdigest()
 
 
+def source_hash() -> str:
+    """Hash of the kernel sources and the compile flags WITHOUT the checkout's absolute include paths: identical on every box for the
+    same sources (profiles/*_conv_traffic.json is stamped with it; bench.py compares)."""
+    h = hashlib.sha256()
+    h.update(" ".join(f for f in CXXFLAGS if not f.startswith("-I")).encode())
+    for d in (CSRC, INCLUDE):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".h", ".hip")):
+                h.update(f.encode())
+                with open(os.path.join(d, f), "rb") as fh:
+                    h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile (if stale) and return the path of libmichigan_hip.so."""
     os.makedirs(OBJ_DIR, exist_ok=True)

@@ -37,8 +37,8 @@ if calls:
 res["commit"] = "$COMMIT"
 import sys
 sys.path.insert(0, "$GRAFT_REPO_ROOT")
-from michigan_amd.build import _fingerprint
-res["kernel_sources"] = _fingerprint()[:16]          # bench.py compares it with the sources it runs on (roofline.traffic_same_kernel_sources)
+from michigan_amd.build import source_hash
+res["kernel_sources"] = source_hash()          # bench.py compares it with the sources it runs on (roofline.traffic_same_kernel_sources)
 res["note"] = "bs 8, 512^2, bf16; per training step unless stated; read side = 2 x FETCH_SIZE (gfx950 correction), KiB -> bytes; run = warm-up step + timed step"
 json.dump(res, open("$OUT/conv_traffic.json", "w"), indent=1)
 print(json.dumps(res))
