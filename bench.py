@@ -136,7 +136,10 @@ def main():
     torch.cuda.set_device(local)
     if world > 1 or os.environ.get("MG_DP_FORCE") == "1":     # MG_DP_FORCE: one-rank RCCL exercise of the DP path (michigan_amd/parallel.py)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            # communicators are created lazily, one ncclCommInitRank per group at its first collective (the long-standing path); MG_NCCL_EAGER=1
+            # binds the device at init instead, and new_group() then derives the sync-BN communicator with ncclCommSplit
+            eager = {"device_id": torch.device("cuda", local)} if os.environ.get("MG_NCCL_EAGER") == "1" else {}
+            dist.init_process_group("nccl", **eager)
         else:
             dist.init_process_group(backend)
     if world != a.gpus:
@@ -167,10 +170,13 @@ def main():
         def step():
             trainer.generated = trainer.pix2pix_model(data, mode="inference")
 
+    def barrier():
+        dist.barrier(device_ids=[local]) if backend == "nccl" else dist.barrier()
+
     for _ in range(a.warmup):
         step()
     if world > 1:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -178,7 +184,7 @@ def main():
     torch.cuda.synchronize()
     dt_own = time.perf_counter() - t0                         # this rank alone: when ITS last kernel finished (before the closing barrier)
     if world > 1:
-        dist.barrier()
+        barrier()
     dt = time.perf_counter() - t0
     per_rank_ms = None
     if world > 1:
@@ -240,7 +246,7 @@ def main():
                 # the PMC passes are separate runs: say whether they were taken on THESE kernel sources (hash of csrc/ + include/ + flags)
                 roof["traffic_same_kernel_sources"] = tj.get("kernel_sources") == source_hash()
     if world > 1:
-        dist.barrier()
+        barrier()
 
     if rank == 0:
         gbatch = a.batch_per_gpu * world

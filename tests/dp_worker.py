@@ -79,7 +79,7 @@ def main(mode):
     if backend == "nccl":
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group("nccl", **({"device_id": device} if os.environ.get("MG_NCCL_EAGER") == "1" else {}))
     elif backend == "gloo_hip":
         local = 0
         torch.cuda.set_device(0)
