@@ -527,12 +527,15 @@ template <typename T>
 int dispatch_conv(ConvK& k, int epilogue, hipStream_t st)
 {
     if (conv_thin_applies(k, ET<T>::DT, epilogue)) return launch_conv_thin(k, st);
+    if (conv_thin_taps_applies(k, ET<T>::DT, epilogue)) return launch_conv_thin_taps(k, st);
     if (conv_dot_applies(k, ET<T>::DT, epilogue)) return launch_conv_dot(k, ET<T>::DT, st);
     if (halo_applies<T>(k)) return launch_conv_halo(k, ET<T>::DT, epilogue, st);
     return epilogue == MG_EPI_SPADE ? dispatch_tiles<T, MG_EPI_SPADE>(k, st) : dispatch_tiles<T, MG_EPI_PLAIN>(k, st);
 }
 
 }  // namespace
+
+float* mg_stream_scratch(hipStream_t st, size_t bytes) { return splitk_workspace(st, bytes); }
 
 extern "C" int mg_conv_taps(const mg_conv_desc* d, void* stream)
 {
@@ -585,7 +588,7 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 4 && (value == 0 || value == 1)) { g_mg_conv_halo_big = value; return MG_OK; }
     if (key == 5 && (value == 0 || value == 1)) { g_mg_conv_splitk = value; return MG_OK; }
     if (key == 17 && (value == 0 || value == 1)) { g_mg_conv_splitk_wide = value; return MG_OK; }
-    if (key == 6 && (value == 0 || value == 1)) { g_mg_conv_thin = value; return MG_OK; }
+    if (key == 6 && value >= 0 && value <= 2) { g_mg_conv_thin = value; return MG_OK; }
     if (key == 7 && (value == 0 || value == 1)) { g_mg_conv_wide = value; return MG_OK; }
     if (key == 8 && (value == 0 || value == 1)) { g_mg_conv_dot = value; return MG_OK; }
     if (key == 9 && (value == 3 || value == 4)) { g_mg_conv_halo_ring = value; return MG_OK; }

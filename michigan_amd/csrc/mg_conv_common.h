@@ -659,5 +659,7 @@ struct LinearPixMap {
 int launch_conv_halo(ConvK& k, int dtype, int epilogue, hipStream_t st);   // mg_conv_halo.hip
 bool conv_thin_applies(const ConvK& k, int dtype, int epilogue);            // mg_conv_thin.hip
 int launch_conv_thin(ConvK& k, hipStream_t st);
+bool conv_thin_taps_applies(const ConvK& k, int dtype, int epilogue);       // mg_conv_thin.hip: any <= 7x7 window, stride 1 | 2
+int launch_conv_thin_taps(ConvK& k, hipStream_t st);
 bool conv_dot_applies(const ConvK& k, int dtype, int epilogue);             // mg_conv_dot.hip
 int launch_conv_dot(ConvK& k, int dtype, hipStream_t st);

@@ -17,7 +17,7 @@
 #include "mg_conv_common.h"
 #include "mg_wgrad_common.h"
 
-int g_mg_conv_thin = 1;            // mg_set_option(6, v): 0 = 8-channel 3x3 convs stay on the tap-list kernel
+int g_mg_conv_thin = 2;            // mg_set_option(6, v): 0 = 8-channel convs stay on the tap-list kernel, 1 = only the 3x3 / stride-1 ones leave it
 
 namespace {
 
@@ -147,6 +147,170 @@ int launch_thin(ConvK& k, hipStream_t st)
     return MG_OK;
 }
 
+
+// ---- any tap window over an 8-channel input (7x7 first conv of the background encoder, the discriminator's 4x4 / stride-2 first conv,
+// the appearance encoder's 3x3 / stride-2 first partial conv) ------------------------------------------------------------------------
+// Same GEMM view as above -- one tap's 8 channels are the 8 K values a lane owns -- but the window no longer fits the register file
+// (49 taps x 64 channels = 50 KiB), so the packed weights sit in LDS for the whole launch ([tap][co][8], a lane's A fragment is one
+// conflict-free ds_read_b128) next to the tile's input halo ((8-1)*S + KH rows x (32-1)*S + KW pixels, 16 bytes each); the B fragment of
+// K step s is one ds_read_b128 at the lane's pixel * S plus the byte offset of tap 2s + hi (a 64-entry table in LDS, filled from the
+// kernel arguments).  The tap-list kernel gathered each pixel's K row as four separate 16-byte taps into its staging image: 230-400
+// TFLOP/s and 1.1 TB/s of output on these layers (profiles/r03_conv_census.txt).  Output widths need not be multiples of the tile.
+template <int CS, int S>
+__global__ __launch_bounds__(256, 2) void conv_thin_taps_kernel(const ConvK d, const int ntiles, const int HH, const int HW,
+                                                                const int dy0, const int dx0, const int nsteps)
+{
+    constexpr int NB = 2, CH = NB * 4, ROW = NB * 64, RPW = 2 * CS, RB = 2, WROWS = CS * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int half = CS == 2 ? (wave >> 1) : 0, r0 = CS == 2 ? (wave & 1) * RPW : wave * RPW;
+    const int cb = half * 64;
+    unsigned char* const wl = smem;
+    unsigned char* const halo = wl + nsteps * 2 * WROWS * 16;
+    int* const tofs = reinterpret_cast<int*>(halo + HH * HW * 16);
+    float* const bias_s = reinterpret_cast<float*>(tofs + MG_MAX_TAPS);
+    unsigned char* const stage = reinterpret_cast<unsigned char*>(bias_s + WROWS) + wave * (32 * ROW);
+
+    if (tid < WROWS) bias_s[tid] = (d.bias && tid < d.Cout_gemm) ? d.bias[tid] : 0.f;
+    if (tid < MG_MAX_TAPS) {                                     // d.tap[] holds byte offsets into the halo here (launch_thin_taps)
+        int v = 0;
+#pragma unroll
+        for (int t = 0; t < MG_MAX_TAPS; ++t) v = (tid == t) ? d.tap[t] : v;
+        tofs[tid] = v;
+    }
+    {
+        const uint16_t* __restrict__ Wt = reinterpret_cast<const uint16_t*>(d.wt);
+        for (int i = tid; i < nsteps * 2 * WROWS; i += 256) {
+            const int t = i / WROWS, row = i % WROWS;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (t < d.ntaps) v = *reinterpret_cast<const uint4*>(Wt + ((size_t)t * d.CoutP + row) * 8);
+            *reinterpret_cast<uint4*>(wl + i * 16) = v;
+        }
+    }
+    const float neg = d.act == MG_ACT_NONE ? 1.f : (d.act == MG_ACT_RELU ? 0.f : d.slope);
+    const bool relu = d.act == MG_ACT_RELU;
+    const uint16_t* __restrict__ In = reinterpret_cast<const uint16_t*>(d.in);
+    unsigned char* __restrict__ Out = reinterpret_cast<unsigned char*>(d.out);
+    const int tpi = d.tiles_y * d.tiles_x;
+    const unsigned char* const wa = wl + (hi * WROWS + cb + l31) * 16;       // this lane's A row of tap `hi`; +2 taps per K step
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int img = tile / tpi, tr = tile - img * tpi;
+        const int y0 = (tr / d.tiles_x) * THIN_TH, x0 = (tr % d.tiles_x) * THIN_TW;
+        __syncthreads();                                         // previous tile's halo reads are done (first tile: weights, table, bias visible)
+        for (int i = tid; i < HH * HW; i += 256) {
+            const int hy = i / HW, hx = i - hy * HW;
+            const int gy = y0 * S + dy0 + hy, gx = x0 * S + dx0 + hx;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win)
+                v = *reinterpret_cast<const uint4*>(In + ((size_t)(img * d.Hin + gy) * d.Win + gx) * 8);
+            *reinterpret_cast<uint4*>(halo + i * 16) = v;
+        }
+        __syncthreads();
+        // two rows of the wave advance together: one pair of A reads feeds 4 MFMAs (a row at a time the weight reads alone were two thirds
+        // of the LDS traffic, ~190 of the 256 B/clk the LDS delivers with two workgroups per CU)
+#pragma unroll 1
+        for (int rg = 0; rg < RPW; rg += RB) {
+        if (y0 + r0 + rg >= d.Hj) break;                         // wave-uniform
+        const unsigned char* const bb = halo + (((r0 + rg) * S) * HW + l31 * S) * 16;
+        f32x16_t acc[RB][NB];
+#pragma unroll
+        for (int mb = 0; mb < RB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4_t bq = *reinterpret_cast<const f32x4_t*>(bias_s + cb + nb * 32 + g * 8 + hi * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mb][nb][g * 4 + e] = bq[e];
+                }
+#pragma unroll 5
+        for (int s = 0; s < nsteps; ++s) {
+            const int o = tofs[2 * s + hi];
+            const bf16x8_t a0 = *reinterpret_cast<const bf16x8_t*>(wa + s * (2 * WROWS * 16));
+            const bf16x8_t a1 = *reinterpret_cast<const bf16x8_t*>(wa + s * (2 * WROWS * 16) + 32 * 16);
+#pragma unroll
+            for (int mb = 0; mb < RB; ++mb) {                   // rows past the image read halo rows that exist (zeros or real pixels); never stored
+                const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(bb + o + mb * (S * HW * 16));
+                acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc[mb][0], 0, 0, 0);
+                acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc[mb][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < RB; ++mb) {
+            const int y = y0 + r0 + rg + mb;
+            if (y >= d.Hj) break;                                // wave-uniform
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 u;
+                    u.x = f2bf2(mg_act_fast(acc[mb][nb][g * 4 + 0], neg, relu), mg_act_fast(acc[mb][nb][g * 4 + 1], neg, relu));
+                    u.y = f2bf2(mg_act_fast(acc[mb][nb][g * 4 + 2], neg, relu), mg_act_fast(acc[mb][nb][g * 4 + 3], neg, relu));
+                    const int c = nb * 4 + g;
+                    *reinterpret_cast<uint2*>(stage + l31 * ROW + ((c ^ ((l31 >> 1) & (CH - 1))) << 4) + hi * 8) = u;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const size_t orow = (size_t)(img * d.Hout + y) * d.Wout + x0;
+            const int pmax = d.Wout - x0;                        // ragged last tile of a row
+#pragma unroll
+            for (int it = 0; it < CH / 2; ++it) {
+                const int q = it * 64 + lane;
+                const int p = q / CH, c = q % CH;
+                const uint4 v = *reinterpret_cast<const uint4*>(stage + p * ROW + ((c ^ ((p >> 1) & (CH - 1))) << 4));
+                const int co = cb + c * 8;
+                if (co < d.Cout && p < pmax)
+                    *reinterpret_cast<uint4*>(Out + ((orow + p) * d.Cout + co) * 2) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                     // stage is rewritten by the next row
+        }
+        }
+    }
+}
+
+struct ThinTapsGeom { int S, dy0, dx0, KH, KW, HH, HW, nsteps, CS, lds; long ntiles; };
+
+bool thin_taps_geom(const ConvK& k, ThinTapsGeom& g)
+{
+    if (k.isy != k.isx || (k.isy != 1 && k.isy != 2) || k.ntaps > 50) return false;
+    int dy0 = 127, dx0 = 127, dy1 = -128, dx1 = -128;
+    for (int t = 0; t < k.ntaps; ++t) {
+        const int dy = (int)(short)(k.tap[t] & 0xffff), dx = k.tap[t] >> 16;
+        dy0 = dy < dy0 ? dy : dy0; dy1 = dy > dy1 ? dy : dy1; dx0 = dx < dx0 ? dx : dx0; dx1 = dx > dx1 ? dx : dx1;
+    }
+    g.S = k.isy; g.dy0 = dy0; g.dx0 = dx0; g.KH = dy1 - dy0 + 1; g.KW = dx1 - dx0 + 1;
+    if (g.KH > 7 || g.KW > 7) return false;
+    g.HH = (THIN_TH - 1) * g.S + g.KH; g.HW = (THIN_TW - 1) * g.S + g.KW;
+    g.nsteps = (k.ntaps + 1) / 2;
+    g.CS = k.Cout_gemm <= 64 ? 1 : 2;
+    g.lds = g.nsteps * 2 * g.CS * 64 * 16 + g.HH * g.HW * 16 + MG_MAX_TAPS * 4 + g.CS * 64 * 4 + 4 * 32 * 128;
+    g.ntiles = (long)k.N * ((k.Hj + THIN_TH - 1) / THIN_TH) * ((k.Wj + THIN_TW - 1) / THIN_TW);
+    return g.lds <= 80 * 1024 && g.ntiles >= 64 && g.ntiles <= 0x7fffffffL;
+}
+
+template <int CS, int S>
+int launch_thin_taps(ConvK& k, const ThinTapsGeom& g, hipStream_t st)
+{
+    k.tiles_y = (k.Hj + THIN_TH - 1) / THIN_TH;
+    k.tiles_x = (k.Wj + THIN_TW - 1) / THIN_TW;
+    int ofs[MG_MAX_TAPS];
+    for (int t = 0; t < MG_MAX_TAPS; ++t) {
+        const int tc = t < k.ntaps ? t : 0;                      // the odd tap of the last K step meets zero weights: any valid address
+        const int dy = (int)(short)(k.tap[tc] & 0xffff), dx = k.tap[tc] >> 16;
+        ofs[t] = ((dy - g.dy0) * g.HW + (dx - g.dx0)) * 16;
+    }
+    for (int t = 0; t < MG_MAX_TAPS; ++t) k.tap[t] = ofs[t];
+    auto kern = conv_thin_taps_kernel<CS, S>;
+    static bool attr_done = false;
+    if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_done = true; }
+    const long grid = g.ntiles < 512 ? g.ntiles : 512;           // 2 workgroups per CU, each walking tiles
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), g.lds, st, k, (int)g.ntiles, g.HH, g.HW, g.dy0, g.dx0, g.nsteps);
+    MG_CHECK_LAUNCH("mg_conv_taps(thin, tap list)");
+    return MG_OK;
+}
+
 // ---- weight gradient of the same layers ---------------------------------------------------------------------
 // dW[tap][co][ci] = sum over pixels of dY[p][co] * X[p + tap][ci] (+ dbias[co] = sum dY[p][co]): a GEMM with
 // M = co, N = (tap, ci) = 72 columns (three 32-column MFMA blocks) and K = pixels, bound by reading dY once.
@@ -267,6 +431,137 @@ __global__ __launch_bounds__(256, 4) void wgrad3x3_thin_kernel(const Wg3K d, con
     }
 }
 
+
+// ---- weight gradient over any tap window (the layers conv_thin_taps_kernel runs forward) ------------------------------------------------
+// dW[tap][co][ci] = sum over output pixels of dY[p][co] * X[p * S + tap][ci]: M = 64 channels of dY (two 32-row blocks), N = (tap, ci) in
+// 32-column blocks of four taps (13 blocks for a 7x7 window), K = pixels.  The four waves are 2 row blocks x 2 column groups of NBW
+// blocks; a workgroup walks 4-row x 32-pixel tiles of dY with the matching X halo in LDS ((4-1)*S + KH rows x (32-1)*S + KW pixels) and
+// keeps its accumulators in registers; both fragments are ds_read_b64_tr_b16 transposes as in wgrad3x3_thin_kernel (for B the lane's
+// K row is its pixel * S shifted by the column's tap).  dW is 100 KiB for the 7x7 layer, so a pass of atomics per workgroup would cost
+// more than the GEMM: every workgroup stores its partial dW into its own slab of a scratch buffer and a finishing launch adds the slabs
+// in workgroup order (bit-reproducible whether or not the caller asked for deterministic gradients).
+template <int NBW, int S>
+__global__ __launch_bounds__(256, 2) void wgrad_thin_taps_kernel(const WgT d, const int ntiles, const int tiles_y, const int tiles_x)
+{
+    constexpr int RBA = 128, PPA = 8;                            // dY bytes / 16-byte pieces per pixel (Cg == 64)
+    constexpr int APT = WTH * 32 * PPA / 256;                    // dY pieces per thread and tile (4)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int hbytes = d.HH * d.HW * 16;
+    unsigned char* const halo = smem;
+    unsigned char* const dyt = smem + hbytes;
+    int* const tofs = reinterpret_cast<int*>(dyt + WTH * 32 * RBA);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int mblk = wave & 1, ng = wave >> 1;
+    auto swz = [](int row) { return (row >> 1) & 1; };            // in 64-byte blocks
+
+    if (tid < MG_MAX_TAPS) {                                     // d.tap[] = pixel offsets of the taps inside the halo
+        int v = 0;
+#pragma unroll
+        for (int t = 0; t < MG_MAX_TAPS; ++t) v = (tid == t) ? d.tap[t] : v;
+        tofs[tid] = v;
+    }
+    __syncthreads();
+    const int i16 = lane & 15, g2 = lane >> 4;
+    const int rsub = (g2 >> 1) * 8 + (i16 >> 2);
+    const int csub = ((g2 & 1) * 16 + (i16 & 3) * 4) * 2;
+    int boff[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        const int n = (ng * NBW + nb) * 32 + (g2 & 1) * 16 + (i16 & 3) * 4;   // first of the lane's 4 columns: tap n / 8, channels n % 8 ..
+        const int tap = (n >> 3) < d.ntaps ? (n >> 3) : 0;       // columns past the window feed accumulator columns nobody stores
+        boff[nb] = (tofs[tap] + rsub * S) * 16 + ((n >> 2) & 1) * 8;
+    }
+
+    f32x16_t acc[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    float bsum = 0.f;
+
+    const uint16_t* __restrict__ X = reinterpret_cast<const uint16_t*>(d.x);
+    const uint16_t* __restrict__ DY = reinterpret_cast<const uint16_t*>(d.dy);
+    const int tpi = tiles_y * tiles_x;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int img = tile / tpi, tr = tile - img * tpi;
+        const int y0 = (tr / tiles_x) * WTH, x0 = (tr % tiles_x) * THIN_TW;
+        __syncthreads();
+        for (int i = tid; i < d.HH * d.HW; i += 256) {
+            const int hy = i / d.HW, hx = i - hy * d.HW;
+            const int gy = y0 * S + d.dy0 + hy, gx = x0 * S + d.dx0 + hx;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win)
+                v = *reinterpret_cast<const uint4*>(X + ((size_t)(img * d.Hin + gy) * d.Win + gx) * 8);
+            *reinterpret_cast<uint4*>(halo + i * 16) = v;
+        }
+        uint4 av[APT];
+#pragma unroll
+        for (int j = 0; j < APT; ++j) {
+            const int g = j * 256 + tid, prow = g / PPA, slot = g % PPA;
+            const int y = y0 + (prow >> 5), x = x0 + (prow & 31);
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (y < d.Hj && x < d.Wj) v = *reinterpret_cast<const uint4*>(DY + ((size_t)(img * d.Hj + y) * d.Wj + x) * 64 + slot * 8);
+            av[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < APT; ++j) {
+            const int g = j * 256 + tid, prow = g / PPA, slot = g % PPA;
+            *reinterpret_cast<uint4*>(dyt + prow * RBA + ((slot ^ (swz(prow) << 2)) << 4)) = av[j];
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int kstep = 0; kstep < WTH * 2; ++kstep) {
+            const int r = kstep >> 1, ks = kstep & 1;
+            const int pr = r * 32 + ks * 16 + rsub;
+            const unsigned char* pa = dyt + pr * RBA + ((mblk * 64 + csub) ^ (swz(pr) << 6));
+            const thin_s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((thin_lds_s16x4_p)(pa));
+            const thin_s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((thin_lds_s16x4_p)(pa + 4 * RBA));
+            const bf16x8_t a = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+            if (ng == 0) {                                       // wave-uniform: one column group sums the bias gradient
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+                const u32x4_t w = __builtin_bit_cast(u32x4_t, a);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bsum += __uint_as_float(w[j] << 16) + __uint_as_float(w[j] & 0xffff0000u);
+            }
+            const unsigned char* pb = halo + ((r * S) * d.HW + ks * 16 * S) * 16;
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                const thin_s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((thin_lds_s16x4_p)(pb + boff[nb]));
+                const thin_s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((thin_lds_s16x4_p)(pb + boff[nb] + 64 * S));
+                const bf16x8_t b = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
+            }
+        }
+    }
+
+    float* const slab = d.ws + (size_t)blockIdx.x * d.slab;      // every element of the slab is written by exactly one lane
+    if (d.has_bias && ng == 0) {
+        const float t = bsum + __shfl_xor(bsum, 32);             // the two K halves of the row
+        if (hi == 0) slab[(size_t)d.ntaps * 64 * 8 + mblk * 32 + l31] = t;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        const int n = (ng * NBW + nb) * 32 + l31, tap = n >> 3, ci = n & 7;
+        if (tap < d.ntaps) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                slab[(size_t)(tap * 64 + co) * 8 + ci] = acc[nb][r];
+            }
+        }
+    }
+}
+
+template <int NBW, int S>
+int launch_wthin_taps(const WgT& k, int grid, long ntiles, int tiles_y, int tiles_x, hipStream_t st)
+{
+    const int lds = k.HH * k.HW * 16 + WTH * 32 * 128 + MG_MAX_TAPS * 4;
+    hipLaunchKernelGGL((wgrad_thin_taps_kernel<NBW, S>), dim3((unsigned)grid), dim3(256), lds, st, k, (int)ntiles, tiles_y, tiles_x);
+    MG_CHECK_LAUNCH("mg_conv_wgrad(thin, tap list)");
+    return MG_OK;
+}
+
 template <int MB>
 int launch_wthin(Wg3K& k, hipStream_t st, int* nsplit, bool dry)
 {
@@ -304,6 +599,24 @@ bool conv_thin_applies(const ConvK& k, int dtype, int epilogue)
     return (long)k.N * ((k.Hin + THIN_TH - 1) / THIN_TH) * (k.Win / THIN_TW) >= 64;
 }
 
+// bf16, Cin == 8, any window of at most 7 x 7 taps at stride 1 or 2 onto the whole output grid (osy = osx = 1), plain epilogue
+bool conv_thin_taps_applies(const ConvK& k, int dtype, int epilogue)
+{
+    if (g_mg_conv_thin < 2 || dtype != MG_BF16 || epilogue != MG_EPI_PLAIN) return false;
+    if (k.Cin != 8 || k.osy != 1 || k.osx != 1 || k.ooy != 0 || k.oox != 0 || k.Hout != k.Hj || k.Wout != k.Wj) return false;
+    if (k.resid || k.x || k.act == MG_ACT_TANH || (k.Cout & 7) || k.Cout_gemm > 128 || k.Cout_gemm < 32) return false;
+    ThinTapsGeom g;
+    return thin_taps_geom(k, g);
+}
+
+int launch_conv_thin_taps(ConvK& k, hipStream_t st)
+{
+    ThinTapsGeom g;
+    if (!thin_taps_geom(k, g)) return mg_fail(MG_ERR_UNSUPPORTED, "mg_conv_taps(thin, tap list): geometry");
+    if (g.CS == 1) return g.S == 1 ? launch_thin_taps<1, 1>(k, g, st) : launch_thin_taps<1, 2>(k, g, st);
+    return g.S == 1 ? launch_thin_taps<2, 1>(k, g, st) : launch_thin_taps<2, 2>(k, g, st);
+}
+
 int launch_conv_thin(ConvK& k, hipStream_t st)
 {
     if (k.Cout_gemm <= 64) return launch_thin<1>(k, st);
@@ -321,4 +634,62 @@ bool wgrad_thin_applies(const Wg3K& k)
 int launch_wgrad_thin(Wg3K& k, hipStream_t st, int* nsplit, bool dry)
 {
     return k.Cg == 64 ? launch_wthin<2>(k, st, nsplit, dry) : launch_wthin<4>(k, st, nsplit, dry);
+}
+
+// bf16, Cin == 8, Cg == 64, any window of at most 7 x 7 taps at stride 1 or 2 (not the 3x3 / stride-1 / same-size case of the kernel above)
+static bool wgrad_thin_taps_geom(const mg_wgrad_desc* d, WgT& k, long& ntiles, int& tiles_y, int& tiles_x, int& nblocks)
+{
+    if (g_mg_conv_thin < 2 || d->dtype != MG_BF16 || d->Cin != 8 || d->Cg != 64 || d->isy != d->isx || (d->isy != 1 && d->isy != 2)) return false;
+    if (d->ntaps > 52) return false;
+    int dy0 = 127, dx0 = 127, dy1 = -128, dx1 = -128;
+    for (int t = 0; t < d->ntaps; ++t) {
+        const int dy = d->tap_dy[t], dx = d->tap_dx[t];
+        dy0 = dy < dy0 ? dy : dy0; dy1 = dy > dy1 ? dy : dy1; dx0 = dx < dx0 ? dx : dx0; dx1 = dx > dx1 ? dx : dx1;
+    }
+    const int KH = dy1 - dy0 + 1, KW = dx1 - dx0 + 1, S = d->isy;
+    if (KH > 7 || KW > 7) return false;
+    k.x = d->x; k.dy = d->dy; k.ws = nullptr; k.N = d->N; k.Hin = d->Hin; k.Win = d->Win; k.Hj = d->Hj; k.Wj = d->Wj; k.ntaps = d->ntaps;
+    k.dy0 = dy0; k.dx0 = dx0; k.HH = (WTH - 1) * S + KH; k.HW = (THIN_TW - 1) * S + KW;
+    k.slab = (long)d->ntaps * 64 * 8 + (d->dbias ? 64 : 0); k.has_bias = d->dbias ? 1 : 0;
+    for (int t = 0; t < MG_MAX_TAPS; ++t) {
+        const int tc = t < d->ntaps ? t : 0;
+        k.tap[t] = (d->tap_dy[tc] - dy0) * k.HW + (d->tap_dx[tc] - dx0);
+    }
+    tiles_y = (d->Hj + WTH - 1) / WTH; tiles_x = (d->Wj + THIN_TW - 1) / THIN_TW;
+    ntiles = (long)d->N * tiles_y * tiles_x;
+    nblocks = (d->ntaps * 8 + 31) / 32;
+    return ntiles >= 64 && ntiles <= 0x7fffffffL;
+}
+
+bool wgrad_thin_taps_applies(const mg_wgrad_desc* d)
+{
+    WgT k; long ntiles; int ty, tx, nb;
+    return wgrad_thin_taps_geom(d, k, ntiles, ty, tx, nb);
+}
+
+// dw / dbias / det_stride as in route_wgrad: det_stride != 0 -> dw IS the caller's slab workspace (dbias behind each slab's dW) and the
+// caller runs the finishing pass; otherwise the slabs go to the stream's scratch buffer and the finishing pass runs here.
+int launch_wgrad_thin_taps(const mg_wgrad_desc* d, hipStream_t st, float* dw, float* dbias, long det_stride, int* nsplit, bool dry)
+{
+    WgT k; long ntiles; int tiles_y, tiles_x, nblocks;
+    if (!wgrad_thin_taps_geom(d, k, ntiles, tiles_y, tiles_x, nblocks)) return mg_fail(MG_ERR_UNSUPPORTED, "mg_conv_wgrad(thin, tap list): geometry");
+    long grid = (ntiles + 7) / 8;                                // at least 8 tiles per slab
+    if (grid > 512) grid = 512;
+    if (nsplit) *nsplit = (int)grid;
+    if (dry) return MG_OK;
+    const long ndw = (long)d->ntaps * 64 * 8;
+    if (det_stride) {
+        if (det_stride != k.slab) return mg_fail(MG_ERR_ARG, "mg_conv_wgrad(thin, tap list): slab stride %ld, expected %ld", det_stride, k.slab);
+        k.ws = dw;
+    } else {
+        k.ws = mg_stream_scratch(st, (size_t)grid * k.slab * sizeof(float));
+        if (k.ws == nullptr) return mg_fail(MG_ERR_LAUNCH, "mg_conv_wgrad(thin, tap list): scratch allocation failed");
+    }
+    const int S = d->isy;
+    int rc;
+    if (nblocks <= 4) rc = S == 1 ? launch_wthin_taps<2, 1>(k, (int)grid, ntiles, tiles_y, tiles_x, st) : launch_wthin_taps<2, 2>(k, (int)grid, ntiles, tiles_y, tiles_x, st);
+    else if (nblocks <= 8) rc = S == 1 ? launch_wthin_taps<4, 1>(k, (int)grid, ntiles, tiles_y, tiles_x, st) : launch_wthin_taps<4, 2>(k, (int)grid, ntiles, tiles_y, tiles_x, st);
+    else rc = S == 1 ? launch_wthin_taps<7, 1>(k, (int)grid, ntiles, tiles_y, tiles_x, st) : launch_wthin_taps<7, 2>(k, (int)grid, ntiles, tiles_y, tiles_x, st);
+    if (rc != MG_OK || det_stride) return rc;
+    return launch_wgrad_det_finish(k.ws, (int)grid, k.slab, dw, ndw, dbias, d->dbias ? 64 : 0, st);
 }

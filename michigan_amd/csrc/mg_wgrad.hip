@@ -328,6 +328,7 @@ int route_wgrad(const mg_wgrad_desc* d, hipStream_t st, float* dw, float* dbias,
         k3.nstg = 0; k3.sps = 0; k3.tiles_m = k3.tiles_n = 0; k3.splitk = 0; k3.det_stride = det_stride;
         if (std3x3 && wgrad_thin_applies(k3)) return launch_wgrad_thin(k3, st, nsplit, dry);
     }
+    if (wgrad_thin_taps_applies(d)) return launch_wgrad_thin_taps(d, st, dw, dbias, det_stride, nsplit, dry);
     if (g_mg_wgrad3x3 && d->dtype == MG_BF16 && (d->flags & 1) && d->ntaps == 9 && d->isy == 1 && d->isx == 1 &&
         d->Hin == d->Hj && d->Win == d->Wj && (d->Win == 16 || d->Win % 32 == 0) && (d->Hin * d->Win) % 32 == 0 &&
         d->Cin >= 64 && d->Cg >= 64) {

@@ -24,3 +24,16 @@ int launch_wgrad_det_finish(const float* ws, int nsplit, long stride, float* dw,
 int launch_wgrad3x3(Wg3K& k, hipStream_t st, int* nsplit = nullptr, bool dry = false);   // mg_wgrad3x3.hip; dry: only report the split count
 bool wgrad_thin_applies(const Wg3K& k);           // mg_conv_thin.hip: 8-channel X, 64 / 128-channel dY
 int launch_wgrad_thin(Wg3K& k, hipStream_t st, int* nsplit = nullptr, bool dry = false);
+
+// generic tap-window weight gradient over an 8-channel X (mg_conv_thin.hip)
+struct WgT {
+    const void* x; const void* dy; float* ws;
+    int N, Hin, Win, Hj, Wj, ntaps;
+    int HH, HW, dy0, dx0;   // halo rows / pixels per row, first tap of the window
+    long slab;              // floats per workgroup slab: ntaps*64*8 (+ 64 bias sums)
+    int has_bias;
+    int tap[MG_MAX_TAPS];   // pixel offset of each tap inside the halo
+};
+bool wgrad_thin_taps_applies(const mg_wgrad_desc* d);
+int launch_wgrad_thin_taps(const mg_wgrad_desc* d, hipStream_t st, float* dw, float* dbias, long det_stride, int* nsplit, bool dry);
+float* mg_stream_scratch(hipStream_t st, size_t bytes);   // mg_conv.hip: grow-only fp32 scratch, one buffer per stream

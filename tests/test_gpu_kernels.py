@@ -464,7 +464,7 @@ def test_thin_conv_8_channel_input(cout, H, W, act, with_bias):
     try:
         y_taps = ops.conv2d(x, w, b, padding=1, act=code)
     finally:
-        be.mg_set_option(6, 1)
+        be.mg_set_option(6, 2)
     yr = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.bfloat16().float(), b, padding=1)
     yr = {"relu": torch.relu, "lrelu": lambda t: torch.nn.functional.leaky_relu(t, 0.2), "none": lambda t: t}[act](yr)
     _close("thin conv vs torch", y, yr.permute(0, 2, 3, 1), TOL["bf16"])
@@ -485,7 +485,7 @@ def test_thin_wgrad_8_channel_input(cg, H, W, want_bias):
     try:
         res_taps = ops.conv_wgrad(x, dy, 3, 3, 1, 1, want_bias=want_bias)
     finally:
-        be.mg_set_option(6, 1)
+        be.mg_set_option(6, 2)
     w = torch.zeros(cg, 8, 3, 3, device="cuda", requires_grad=True)
     b = torch.zeros(cg, device="cuda", requires_grad=True)
     torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w, b, padding=1).backward(dy.float().permute(0, 3, 1, 2))
@@ -495,6 +495,63 @@ def test_thin_wgrad_8_channel_input(cg, H, W, want_bias):
     _close("thin wgrad vs generic kernel", dw, dw_taps, 1e-4)
     if want_bias:
         _close("thin dbias vs torch", res[1], b.grad, 1e-4)
+
+
+THIN_TAPS_CASES = [  # N, H, W, cout, k, stride, pad, act, bias   (8-channel bf16 input; the layers of the step + ragged variants;
+    # every case has >= 64 forward tiles of 8 x 32 pixels and >= 64 gradient tiles of 4 x 32, the kernels' dispatch thresholds)
+    (4, 70, 70, 64, 7, 1, 0, "relu", True),      # BackgroundEncode2.conv1 on a reflect-padded map (valid 7x7)
+    (4, 128, 96, 64, 4, 2, 2, "lrelu", True),    # discriminator layer 0: 4x4 / stride 2 / pad 2 -> 65 x 49 (ragged tiles)
+    (4, 128, 128, 64, 3, 2, 1, "none", False),   # appearance encoder layer 1: 3x3 / stride 2
+    (2, 130, 75, 128, 5, 1, 2, "relu", True),    # two 64-channel halves, odd sizes
+    (3, 41, 100, 96, 3, 1, 1, "lrelu", True),    # 3x3 / stride 1 whose width the register-weight kernel does not take
+    (2, 67, 100, 64, 5, 1, 2, "none", True),     # 5x5: the 4-block column groups of the gradient kernel
+]
+
+
+@pytest.mark.parametrize("case", THIN_TAPS_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_thin_taps_conv_and_wgrad_any_window(case):
+    """The LDS-weight kernels for ANY <= 7x7 window over an 8-channel bf16 map (7x7 first conv, 4x4 / stride-2 discriminator input
+    conv, 3x3 / stride-2 encoder input conv): forward against torch's fp32 convolution and against the tap-list kernel
+    (mg_set_option(6, 1)); weight / bias gradients (64-channel dY) against torch's fp32 autograd and the generic kernel."""
+    from michigan_amd import ops, _cabi
+    N, H, W, cout, k, stride, pad, act, with_bias = case
+    g = torch.Generator().manual_seed(H * 7 + W + cout)
+    x = torch.randn(N, H, W, 8, generator=g).bfloat16().cuda()
+    w = (torch.randn(cout, 8, k, k, generator=g) / (2.0 * k)).cuda()
+    b = torch.randn(cout, generator=g).cuda() if with_bias else None
+    code = {"relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "none": ops.ACT_NONE}[act]
+    be = _cabi.backend()
+    y = ops.conv2d(x, w, b, stride=stride, padding=pad, act=code)
+    be.mg_set_option(6, 1)
+    try:
+        y_taps = ops.conv2d(x, w, b, stride=stride, padding=pad, act=code)
+    finally:
+        be.mg_set_option(6, 2)
+    yr = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.bfloat16().float(), b, stride=stride, padding=pad)
+    yr = {"relu": torch.relu, "lrelu": lambda t: torch.nn.functional.leaky_relu(t, 0.2), "none": lambda t: t}[act](yr)
+    assert tuple(y.shape) == tuple(yr.permute(0, 2, 3, 1).shape)
+    _close("thin taps conv vs torch", y, yr.permute(0, 2, 3, 1), TOL["bf16"])
+    _close("thin taps conv vs tap-list kernel", y, y_taps, TOL["bf16"])
+    if cout != 64:
+        return
+    dy = torch.randn(N, yr.shape[2], yr.shape[3], 64, generator=g).bfloat16().cuda()
+    res = ops.conv_wgrad(x, dy, k, k, stride, pad, want_bias=with_bias)
+    res2 = ops.conv_wgrad(x, dy, k, k, stride, pad, want_bias=with_bias)
+    be.mg_set_option(6, 1)
+    try:
+        res_taps = ops.conv_wgrad(x, dy, k, k, stride, pad, want_bias=with_bias)
+    finally:
+        be.mg_set_option(6, 2)
+    wz = torch.zeros(64, 8, k, k, device="cuda", requires_grad=True)
+    bz = torch.zeros(64, device="cuda", requires_grad=True)
+    torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), wz, bz, stride=stride, padding=pad).backward(dy.float().permute(0, 3, 1, 2))
+    dw_ref = wz.grad.permute(2, 3, 0, 1).reshape(k * k, 64, 8)
+    dw, dw2, dw_taps = (res[0], res2[0], res_taps[0]) if with_bias else (res, res2, res_taps)
+    _close("thin taps wgrad vs torch", dw, dw_ref, 1e-4)
+    _close("thin taps wgrad vs generic kernel", dw, dw_taps, 1e-4)
+    assert torch.equal(dw, dw2), "slab sums in workgroup order: two launches must agree bit for bit"
+    if with_bias:
+        _close("thin taps dbias vs torch", res[1], bz.grad, 1e-4)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])

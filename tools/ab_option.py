@@ -1,4 +1,4 @@
-"""A/B a kernel option on the full training step inside one process: tools/ab_option.py <key> (GPU box)."""
+"""A/B a kernel option on the full training step inside one process: tools/ab_option.py <key> [value_a value_b] (GPU box)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import michigan_amd  # noqa: F401
@@ -7,6 +7,7 @@ from michigan_amd import _cabi
 from michigan_amd.model import Pix2PixTrainer, default_options
 from michigan_amd.synth import synth_batch
 key = int(sys.argv[1])
+vals = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1, 0)
 opt = default_options(crop_size=512, gpu_ids=[0], compute_dtype="bf16")
 tr = Pix2PixTrainer(opt)
 data = {k: v.cuda() for k, v in synth_batch(8, 512, seed=1234).items()}
@@ -14,7 +15,7 @@ def step():
     tr.run_generator_one_step(data); tr.run_discriminator_one_step(data)
 for _ in range(3): step()
 for rep in range(3):
-    for v in (1, 0):
+    for v in vals:
         _cabi.backend().mg_set_option(key, v)
         step(); torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(6): step()

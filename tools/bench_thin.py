@@ -34,7 +34,7 @@ def main():
                 tf = timeit(lambda: ops.conv2d(x, w, b, padding=1, act=ops.ACT_RELU))
             tw = timeit(lambda: ops.conv_wgrad(x, gy, 3, 3, 1, 1, want_bias=True))
             row.append((tf, tw))
-        be.mg_set_option(6, 1)
+        be.mg_set_option(6, 2)
         out_gb = n * hw * hw * cout * 2 / 1e9
         print(f"N{n} {hw}x{hw}x8 -> {cout}: fwd {row[0][0]*1e3:7.1f} -> {row[1][0]*1e3:7.1f} us ({out_gb / row[1][0] * 1e3:.2f} TB/s out)"
               f"   wgrad {row[0][1]*1e3:7.1f} -> {row[1][1]*1e3:7.1f} us ({out_gb / row[1][1] * 1e3:.2f} TB/s dy)")
