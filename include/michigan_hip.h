@@ -460,7 +460,8 @@ int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* o
 /* Tuning switches for A/B measurements (value 0 / 1, all default 1): key 0 = conv pipeline (0 register-staged
  * double buffer, 1 LDS-DMA ring); 1 = allow 256x256 tiles; 2 = 3x3 halo-tile kernel; 3 = kernel-row 3x3 weight-
  * gradient kernel; 4 = 128-channel x 16x16-pixel halo tiles; 5 = split-K for low-resolution long-K convolutions;
- * 6 = register-weight kernels for 3x3 convolutions over an 8-channel input (forward and weight gradient);
+ * 6 = kernels for convolutions over an 8-channel input, forward and weight gradient (0 none, 1 only the register-weight 3x3 / stride-1
+ *     ones, 2 default: also the LDS-weight kernels for any window of at most 7x7 taps at stride 1 or 2);
  * 7 = bf16 conv epilogues exchange channel quads between the two half-waves (v_permlane32_swap) and store 16 bytes per lane;
  * 8 = wave-per-pixel dot-product kernel for convolutions with <= 4 output channels over >= 128 input channels (the discriminators' heads).
  * 9 = weight-slab ring depth of the big halo tile (3 default, or 4); 15 = 1: the SPADE halo kernel loads x in its epilogue instead of
