@@ -550,6 +550,15 @@ def test_thin_taps_conv_and_wgrad_any_window(case):
     _close("thin taps wgrad vs torch", dw, dw_ref, 1e-4)
     _close("thin taps wgrad vs generic kernel", dw, dw_taps, 1e-4)
     assert torch.equal(dw, dw2), "slab sums in workgroup order: two launches must agree bit for bit"
+    prev = ops.WGRAD_DETERMINISTIC
+    ops.set_deterministic(True)                       # the caller's slab workspace + the library's finishing pass: the same sums in the same order
+    try:
+        res_det = ops.conv_wgrad(x, dy, k, k, stride, pad, want_bias=with_bias)
+    finally:
+        ops.set_deterministic(prev)
+    assert torch.equal(dw, res_det[0] if with_bias else res_det)
+    if with_bias:
+        assert torch.equal(res[1], res_det[1])
     if with_bias:
         _close("thin taps dbias vs torch", res[1], bz.grad, 1e-4)
 
