@@ -17,6 +17,8 @@
 
 int g_mg_wgrad3x3 = 1;     // mg_set_option(3, v): 0 = always the generic tap-per-workgroup kernel
 
+int g_mg_wgrad_min_stages = 32;      // mg_set_option(18, v): stages (of 32 / 16 pixels) a split of the generic kernel keeps at least
+
 namespace {
 
 constexpr int NTHR = 256;
@@ -277,7 +279,9 @@ int launch_wgrad(WgK& k, hipStream_t st, int* nsplit = nullptr, bool dry = false
     int S = k.splitk;
     if (S <= 0) {
         S = (int)((1536 + base - 1) / base);                 // ~6 workgroups per CU in flight
-        const int maxS = (k.K + KP * 8 - 1) / (KP * 8);        // keep >= 8 stages per split
+        // >= 32 stages per split: every split ends with a pass of atomics over its 128 x 128 tile; with the 8-stage floor the mid-size
+        // stride-2 / 1x1 layers ran 1500 workgroups of 12 stages and took 0.10 ms where 32-stage splits take 0.065 (tools/variant_sweep.py)
+        const int maxS = (k.K + KP * g_mg_wgrad_min_stages - 1) / (KP * g_mg_wgrad_min_stages);
         if (S > maxS) S = maxS;
         if (S < 1) S = 1;
     }
