@@ -254,15 +254,35 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgK d)
         }
 }
 
-// deterministic mode: dst[i] += sum over splits, in split order (fixed): dw for i < ndw, dbias behind it
-__global__ void wgrad_det_finish_kernel(const float* __restrict__ ws, int nsplit, long stride, float* __restrict__ dw, long ndw,
-                                        float* __restrict__ dbias, int nbias)
+// dst[i] += sum over splits in a FIXED order: dw for i < ndw, dbias behind it.  A 256-thread block owns 32 outputs; its 8 thread rows
+// take every 8th split each (in split order), then the 8 row sums are added in row order.  (One thread per output walking all splits
+// was 19 blocks x 512 dependent steps for a 3x3 / 8-channel layer: 100 us behind a 50 us kernel.)
+__global__ __launch_bounds__(256) void wgrad_det_finish_kernel(const float* __restrict__ ws, int nsplit, long stride, float* __restrict__ dw, long ndw,
+                                                               float* __restrict__ dbias, int nbias)
 {
+    __shared__ float red[256];
     const long total = ndw + nbias;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cl = threadIdx.x & 31, row = threadIdx.x >> 5;
+    for (long i0 = blockIdx.x * 32L; i0 < total; i0 += gridDim.x * 32L) {
+        const long i = i0 + cl;
         float a = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) a += ws[(size_t)sp * stride + i];
-        if (i < ndw) dw[i] += a; else dbias[i - ndw] += a;
+        if (i < total) {
+            const float* p = ws + i;
+            int sp = row;
+            for (; sp + 24 < nsplit; sp += 32) {                 // four independent loads in flight
+                const float v0 = p[(size_t)sp * stride], v1 = p[(size_t)(sp + 8) * stride], v2 = p[(size_t)(sp + 16) * stride], v3 = p[(size_t)(sp + 24) * stride];
+                a += v0; a += v1; a += v2; a += v3;
+            }
+            for (; sp < nsplit; sp += 8) a += p[(size_t)sp * stride];
+        }
+        __syncthreads();
+        red[threadIdx.x] = a;
+        __syncthreads();
+        if (row == 0 && i < total) {
+#pragma unroll
+            for (int r = 1; r < 8; ++r) a += red[r * 32 + cl];
+            if (i < ndw) dw[i] += a; else dbias[i - ndw] += a;
+        }
     }
 }
 
@@ -281,7 +301,11 @@ int launch_wgrad(WgK& k, hipStream_t st, int* nsplit = nullptr, bool dry = false
         S = (int)((1536 + base - 1) / base);                 // ~6 workgroups per CU in flight
         // >= 32 stages per split: every split ends with a pass of atomics over its 128 x 128 tile; with the 8-stage floor the mid-size
         // stride-2 / 1x1 layers ran 1500 workgroups of 12 stages and took 0.10 ms where 32-stage splits take 0.065 (tools/variant_sweep.py)
-        const int maxS = (k.K + KP * g_mg_wgrad_min_stages - 1) / (KP * g_mg_wgrad_min_stages);
+        int maxS = (k.K + KP * g_mg_wgrad_min_stages - 1) / (KP * g_mg_wgrad_min_stages);
+        if (base * maxS < 256) {                               // ... unless that leaves CUs idle (tiny layers): down to 4 stages per split
+            const int fill = (int)((256 + base - 1) / base), floor4 = (k.K + KP * 4 - 1) / (KP * 4);
+            maxS = fill < floor4 ? fill : floor4;
+        }
         if (S > maxS) S = maxS;
         if (S < 1) S = 1;
     }
@@ -303,8 +327,8 @@ int launch_wgrad(WgK& k, hipStream_t st, int* nsplit = nullptr, bool dry = false
 int launch_wgrad_det_finish(const float* ws, int nsplit, long stride, float* dw, long ndw, float* dbias, int nbias, hipStream_t st)
 {
     const long total = ndw + nbias;
-    long grid = (total + 255) / 256;
-    if (grid > 4096) grid = 4096;
+    long grid = (total + 31) / 32;
+    if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(wgrad_det_finish_kernel, dim3((unsigned)grid), dim3(256), 0, st, ws, nsplit, stride, dw, ndw, dbias, nbias);
     MG_CHECK_LAUNCH("mg_conv_wgrad(deterministic finish)");
     return MG_OK;

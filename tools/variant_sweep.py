@@ -66,25 +66,33 @@ for (kind, k), ds in groups.items():
     else:
         desc = f"wgrad N{kd['N']} x{kd['Hin']}x{kd['Win']}x{kd['Cin']} dy{kd['Hj']}x{kd['Wj']}x{kd['Cg']} t{kd['ntaps']} s{kd['isy']}"
         variants = list(WG_VARIANTS) + [(f"splitk {s}", (), s) for s in (2, 4, 8, 16, 32, 64, 128)]
-    times = []
-    for name, opts, splitk in variants:
+    def run(opts, splitk, reps):
         for key, v, _ in opts: be.mg_set_option(key, v)
         old = getattr(d, "splitk", None)
         if splitk is not None: d.splitk = splitk
         try:
-            ms = timed(fn, d)
-        except Exception as ex:                       # a variant the shape does not support
+            ms = timed(fn, d, reps)
+        except Exception:                             # a variant the shape does not support
             ms = float("inf")
         if splitk is not None: d.splitk = old
         for key, _, dv in opts: be.mg_set_option(key, dv)
-        times.append((ms, name))
-    base = times[0][0]
-    best = min(times)
+        return ms
+    base = run((), None, 8)
     base_tot += base * len(ds)
-    if best[0] < 0.97 * base:
-        gain_tot += (base - best[0]) * len(ds)
-        rows.append(((base - best[0]) * len(ds), len(ds), base, best[0], best[1], desc))
+    best = None
+    for name, opts, splitk in variants[1:]:
+        v1 = run(opts, splitk, 4)
+        if v1 > 0.96 * base:
+            continue
+        # candidate: interleave default / variant twice more; a win must hold against the FASTEST default and by the SLOWEST variant run
+        d2, v2, d3, v3 = run((), None, 8), run(opts, splitk, 8), run((), None, 8), run(opts, splitk, 8)
+        dmin, vmax = min(base, d2, d3), max(v1, v2, v3)
+        if vmax < 0.96 * dmin and (best is None or vmax < best[0]):
+            best = (vmax, name, dmin)
+    if best is not None:
+        gain_tot += (best[2] - best[0]) * len(ds)
+        rows.append(((best[2] - best[0]) * len(ds), len(ds), best[2], best[0], best[1], desc))
 rows.sort(reverse=True)
-print(f"replayed {len(groups)} unique shapes, {base_tot:.2f} ms per step with the default dispatch; non-default wins (> 3 %): {gain_tot:.3f} ms per step")
+print(f"replayed {len(groups)} unique shapes, {base_tot:.2f} ms per step with the default dispatch; replicated non-default wins (> 4 %, slowest variant run vs fastest default run): {gain_tot:.3f} ms per step")
 for g, n, b, t, name, desc in rows:
     print(f"  -{g:6.3f} ms = {n:2d} x ({b:7.3f} -> {t:7.3f} ms)  {name:26s} {desc}")
