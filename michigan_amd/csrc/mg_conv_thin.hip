@@ -325,7 +325,7 @@ constexpr int WTH = 4;                                           // rows per wei
 constexpr int WHALO_BYTES = (WTH + 2) * THIN_HW * 16;            // 3264
 
 template <int MB>       // 32-channel blocks of dY: Cg == 32 * MB, MB = 2 or 4
-__global__ __launch_bounds__(256, 4) void wgrad3x3_thin_kernel(const Wg3K d, const int ntiles, const int tiles_y, const int tiles_x)
+__global__ __launch_bounds__(256, MB == 4 ? 3 : 4) void wgrad3x3_thin_kernel(const Wg3K d, const int ntiles, const int tiles_y, const int tiles_x)
 {
     constexpr int RBA = MB * 64, PPA = RBA / 16;                 // bytes / 16-byte pieces per dY pixel
     constexpr int KG = 4 / MB;                                   // waves sharing a channel block
@@ -361,19 +361,21 @@ __global__ __launch_bounds__(256, 4) void wgrad3x3_thin_kernel(const Wg3K d, con
     const uint16_t* __restrict__ DY = reinterpret_cast<const uint16_t*>(d.dy);
     const int tpi = tiles_y * tiles_x;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // The next tile's global loads are issued BEFORE this tile's MFMAs and land in registers behind them (the loop used to be load ->
+    // barrier -> compute with nothing in flight during the compute: 3.3 TB/s of dY at four workgroups per CU).
+    uint4 hv = {0u, 0u, 0u, 0u};
+    uint4 av[APT];
+    auto fetch = [&](int tile) {
         const int img = tile / tpi, tr = tile - img * tpi;
         const int y0 = (tr / tiles_x) * WTH, x0 = (tr % tiles_x) * THIN_TW;
-        __syncthreads();
         if (tid < (WTH + 2) * THIN_HW) {
             const int hy = tid / THIN_HW, hx = tid - hy * THIN_HW;
             const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
             uint4 v = {0u, 0u, 0u, 0u};
             if (gy >= 0 && gy < d.H && gx >= 0 && gx < d.W)
                 v = *reinterpret_cast<const uint4*>(X + ((size_t)(img * d.H + gy) * d.W + gx) * 8);
-            *reinterpret_cast<uint4*>(halo + tid * 16) = v;
+            hv = v;
         }
-        uint4 av[APT];
 #pragma unroll
         for (int j = 0; j < APT; ++j) {
             const int g = j * 256 + tid, prow = g / PPA, slot = g % PPA;
@@ -382,12 +384,18 @@ __global__ __launch_bounds__(256, 4) void wgrad3x3_thin_kernel(const Wg3K d, con
             if (y < d.H) v = *reinterpret_cast<const uint4*>(DY + ((size_t)(img * d.H + y) * d.W + x) * d.Cg + slot * 8);
             av[j] = v;
         }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        if (tid < (WTH + 2) * THIN_HW) *reinterpret_cast<uint4*>(halo + tid * 16) = hv;
 #pragma unroll
         for (int j = 0; j < APT; ++j) {
             const int g = j * 256 + tid, prow = g / PPA, slot = g % PPA;
             *reinterpret_cast<uint4*>(dyt + prow * RBA + ((slot ^ (swz(prow) << 2)) << 4)) = av[j];
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
 #pragma unroll
         for (int kk = 0; kk < WTH * 2 / KG; ++kk) {
             const int kstep = kk * KG + kg, r = kstep >> 1, ks = kstep & 1;
@@ -483,19 +491,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_taps_kernel(const WgT d, co
     const uint16_t* __restrict__ DY = reinterpret_cast<const uint16_t*>(d.dy);
     const int tpi = tiles_y * tiles_x;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // the next tile's global loads are issued before this tile's MFMAs (see wgrad3x3_thin_kernel)
+    constexpr int HPT = 3;                                       // halo pieces per thread: HH * HW <= 10 * 69
+    uint4 hv[HPT];
+    uint4 av[APT];
+    const int npix = d.HH * d.HW;
+    auto fetch = [&](int tile) {
         const int img = tile / tpi, tr = tile - img * tpi;
         const int y0 = (tr / tiles_x) * WTH, x0 = (tr % tiles_x) * THIN_TW;
-        __syncthreads();
-        for (int i = tid; i < d.HH * d.HW; i += 256) {
+#pragma unroll
+        for (int q = 0; q < HPT; ++q) {
+            const int i = tid + q * 256;
             const int hy = i / d.HW, hx = i - hy * d.HW;
             const int gy = y0 * S + d.dy0 + hy, gx = x0 * S + d.dx0 + hx;
             uint4 v = {0u, 0u, 0u, 0u};
-            if (gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win)
+            if (i < npix && gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win)
                 v = *reinterpret_cast<const uint4*>(X + ((size_t)(img * d.Hin + gy) * d.Win + gx) * 8);
-            *reinterpret_cast<uint4*>(halo + i * 16) = v;
+            hv[q] = v;
         }
-        uint4 av[APT];
 #pragma unroll
         for (int j = 0; j < APT; ++j) {
             const int g = j * 256 + tid, prow = g / PPA, slot = g % PPA;
@@ -504,12 +517,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_thin_taps_kernel(const WgT d, co
             if (y < d.Hj && x < d.Wj) v = *reinterpret_cast<const uint4*>(DY + ((size_t)(img * d.Hj + y) * d.Wj + x) * 64 + slot * 8);
             av[j] = v;
         }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < HPT; ++q) {
+            const int i = tid + q * 256;
+            if (i < npix) *reinterpret_cast<uint4*>(halo + i * 16) = hv[q];
+        }
 #pragma unroll
         for (int j = 0; j < APT; ++j) {
             const int g = j * 256 + tid, prow = g / PPA, slot = g % PPA;
             *reinterpret_cast<uint4*>(dyt + prow * RBA + ((slot ^ (swz(prow) << 2)) << 4)) = av[j];
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
 #pragma unroll 2
         for (int kstep = 0; kstep < WTH * 2; ++kstep) {
             const int r = kstep >> 1, ks = kstep & 1;
