@@ -530,6 +530,7 @@ int dispatch_conv(ConvK& k, int epilogue, hipStream_t st)
     if (conv_thin_applies(k, ET<T>::DT, epilogue)) return launch_conv_thin(k, st);
     if (conv_thin_taps_applies(k, ET<T>::DT, epilogue)) return launch_conv_thin_taps(k, st);
     if (conv_dot_applies(k, ET<T>::DT, epilogue)) return launch_conv_dot(k, ET<T>::DT, st);
+    if (conv_fewout_applies(k, ET<T>::DT, epilogue)) return launch_conv_fewout(k, st);
     if (halo_applies<T>(k)) return launch_conv_halo(k, ET<T>::DT, epilogue, st);
     return epilogue == MG_EPI_SPADE ? dispatch_tiles<T, MG_EPI_SPADE>(k, st) : dispatch_tiles<T, MG_EPI_PLAIN>(k, st);
 }
@@ -592,7 +593,7 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 6 && value >= 0 && value <= 2) { g_mg_conv_thin = value; return MG_OK; }
     if (key == 18 && value >= 1 && value <= 1024) { g_mg_wgrad_min_stages = value; return MG_OK; }
     if (key == 7 && (value == 0 || value == 1)) { g_mg_conv_wide = value; return MG_OK; }
-    if (key == 8 && (value == 0 || value == 1)) { g_mg_conv_dot = value; return MG_OK; }
+    if (key == 8 && value >= 0 && value <= 2) { g_mg_conv_dot = value; return MG_OK; }
     if (key == 9 && (value == 3 || value == 4)) { g_mg_conv_halo_ring = value; return MG_OK; }
     if (key == 15 && (value == 0 || value == 1)) { g_mg_conv_noxpre = value; return MG_OK; }
     if (key == 13) { g_probe_lo = (unsigned)value; return MG_OK; }

@@ -663,3 +663,5 @@ bool conv_thin_taps_applies(const ConvK& k, int dtype, int epilogue);       // m
 int launch_conv_thin_taps(ConvK& k, hipStream_t st);
 bool conv_dot_applies(const ConvK& k, int dtype, int epilogue);             // mg_conv_dot.hip
 int launch_conv_dot(ConvK& k, int dtype, hipStream_t st);
+bool conv_fewout_applies(const ConvK& k, int dtype, int epilogue);          // mg_conv_dot.hip: <= 16 GEMM rows over 64 input channels
+int launch_conv_fewout(ConvK& k, hipStream_t st);

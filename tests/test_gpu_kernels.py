@@ -563,6 +563,48 @@ def test_thin_taps_conv_and_wgrad_any_window(case):
         _close("thin taps dbias vs torch", res[1], bz.grad, 1e-4)
 
 
+@pytest.mark.parametrize("case", [("img", 3, 3, 1, 1), ("dgrad3x3", 8, 3, 1, 1), ("dgrad4x4s2", 8, 4, 2, 2), ("dgrad3x3s2", 8, 3, 2, 1)], ids=lambda c: c[0])
+def test_few_output_channel_convs_over_64_channels(case):
+    """The 16-row MFMA kernel for <= 16 GEMM rows over a 64-channel bf16 input (mg_conv_dot.hip): conv_img (64 -> 3, tanh) forward and
+    the data gradients that end in an 8-channel network input (stride 1, and the four parity classes of a stride-2 conv with strided
+    stores), ragged tiles, against torch fp32 and against the tap-list kernel (mg_set_option(8, 1))."""
+    from michigan_amd import ops, _cabi
+    name, cnarrow, k, stride, pad = case
+    g = torch.Generator().manual_seed(len(name) + k)
+    be = _cabi.backend()
+    if name == "img":
+        x = torch.randn(3, 72, 100, 64, generator=g).bfloat16().cuda()
+        w = (torch.randn(3, 64, 3, 3, generator=g) / 24).cuda()
+        b = torch.randn(3, generator=g).cuda()
+        y = ops.conv2d(x, w, b, padding=1, act=ops.ACT_TANH)
+        be.mg_set_option(8, 1)
+        try:
+            y_taps = ops.conv2d(x, w, b, padding=1, act=ops.ACT_TANH)
+        finally:
+            be.mg_set_option(8, 2)
+        yr = torch.tanh(torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.bfloat16().float(), b, padding=1)).permute(0, 2, 3, 1)
+        _close("few-output conv vs torch", y[..., :3], yr, TOL["bf16"])
+        _close("few-output conv vs tap-list kernel", y, y_taps, TOL["bf16"])
+        return
+    # data gradient of an 8 -> 64 conv: 64 "input" channels (dy), 8 output channels (dx)
+    x = torch.randn(3, 70, 96, 8, generator=g).bfloat16().cuda().requires_grad_(True)
+    w = (torch.randn(64, 8, k, k, generator=g) / (3.0 * k)).cuda()
+    y = ops.conv2d(x, w, None, stride=stride, padding=pad)
+    gy = torch.randn(y.shape, generator=g).bfloat16().cuda()
+    (dx,) = torch.autograd.grad(y, x, gy)
+    be.mg_set_option(8, 1)
+    try:
+        y2 = ops.conv2d(x, w, None, stride=stride, padding=pad)
+        (dx_taps,) = torch.autograd.grad(y2, x, gy)
+    finally:
+        be.mg_set_option(8, 2)
+    xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, w.bfloat16().float(), None, stride=stride, padding=pad)
+    (dxr,) = torch.autograd.grad(yr, xr, gy.float().permute(0, 3, 1, 2))
+    _close("few-output dgrad vs torch", dx, dxr.permute(0, 2, 3, 1), TOL["bf16"])
+    _close("few-output dgrad vs tap-list kernel", dx, dx_taps, TOL["bf16"])
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("C,H,W", [(64, 200, 176), (136, 97, 131)], ids=str)
 def test_spade_halo_ragged_geometry(C, H, W, dt):
