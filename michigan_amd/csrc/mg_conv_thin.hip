@@ -194,19 +194,36 @@ __global__ __launch_bounds__(256, 2) void conv_thin_taps_kernel(const ConvK d, c
     const int tpi = d.tiles_y * d.tiles_x;
     const unsigned char* const wa = wl + (hi * WROWS + cb + l31) * 16;       // this lane's A row of tap `hi`; +2 taps per K step
 
+    // the next tile's halo is fetched into registers behind this tile's MFMAs and stores
+    constexpr int HPT = 6;                                       // halo pieces per thread: HH * HW <= 20 * 69 = 1380
+    uint4 hv[HPT];
+    const int npix = HH * HW;
+    auto fetch = [&](int tile) {
+        const int img = tile / tpi, tr = tile - img * tpi;
+        const int y0 = (tr / d.tiles_x) * THIN_TH, x0 = (tr % d.tiles_x) * THIN_TW;
+#pragma unroll
+        for (int q = 0; q < HPT; ++q) {
+            const int i = tid + q * 256;
+            const int hy = i / HW, hx = i - hy * HW;
+            const int gy = y0 * S + dy0 + hy, gx = x0 * S + dx0 + hx;
+            uint4 v = {0u, 0u, 0u, 0u};
+            if (i < npix && gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win)
+                v = *reinterpret_cast<const uint4*>(In + ((size_t)(img * d.Hin + gy) * d.Win + gx) * 8);
+            hv[q] = v;
+        }
+    };
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int img = tile / tpi, tr = tile - img * tpi;
         const int y0 = (tr / d.tiles_x) * THIN_TH, x0 = (tr % d.tiles_x) * THIN_TW;
         __syncthreads();                                         // previous tile's halo reads are done (first tile: weights, table, bias visible)
-        for (int i = tid; i < HH * HW; i += 256) {
-            const int hy = i / HW, hx = i - hy * HW;
-            const int gy = y0 * S + dy0 + hy, gx = x0 * S + dx0 + hx;
-            uint4 v = {0u, 0u, 0u, 0u};
-            if (gy >= 0 && gy < d.Hin && gx >= 0 && gx < d.Win)
-                v = *reinterpret_cast<const uint4*>(In + ((size_t)(img * d.Hin + gy) * d.Win + gx) * 8);
-            *reinterpret_cast<uint4*>(halo + i * 16) = v;
+#pragma unroll
+        for (int q = 0; q < HPT; ++q) {
+            const int i = tid + q * 256;
+            if (i < npix) *reinterpret_cast<uint4*>(halo + i * 16) = hv[q];
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
         // two rows of the wave advance together: one pair of A reads feeds 4 MFMAs (a row at a time the weight reads alone were two thirds
         // of the LDS traffic, ~190 of the 256 B/clk the LDS delivers with two workgroups per CU)
 #pragma unroll 1
