@@ -16,7 +16,8 @@
 namespace {
 
 constexpr int PACK_PER_BLOCK = 1024;      // destination elements per workgroup (4 per thread)
-constexpr int K1_ROWS = 32;               // rows of W per W^T u partial block
+constexpr int K1_ROWS = 128;              // rows of W per W^T u partial block (32: the per-layer finish walked 32 partials per column, 53 us)
+constexpr int K1_COLS = 1024;             // columns per block: four per thread, 16-byte loads
 constexpr int K3_ROWS = 4;                // rows of W per W v block (one wave each)
 
 __device__ __forceinline__ int row_to_co2(int r, int cout, bool two, int& which)
@@ -120,13 +121,30 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(const mg_sn_layer* __restri
 {
     const mg_sn_layer& L = layers[block_layer[blockIdx.x]];
     const int rel = blockIdx.x - L.first_block_k1;
-    const int cblocks = (L.cols + 255) >> 8;
-    const int chunk = rel / cblocks, c = (rel % cblocks) * 256 + threadIdx.x;
+    const int cblocks = (L.cols + K1_COLS - 1) / K1_COLS;
+    const int chunk = rel / cblocks, c = ((rel % cblocks) * 256 + threadIdx.x) * 4;
     if (c >= L.cols) return;
     const int r0 = chunk * K1_ROWS, r1 = min(r0 + K1_ROWS, L.rows);
-    float acc = 0.f;
-    for (int r = r0; r < r1; ++r) acc += L.w[(size_t)r * L.cols + c] * L.u[r];
-    L.partial[(size_t)chunk * L.cols + c] = acc;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((L.cols & 3) == 0 && (((uintptr_t)L.w | (uintptr_t)L.partial) & 15) == 0) {   // rows stay 16-byte aligned: one dwordx4 load per row (4x the bytes in flight)
+        const float* __restrict__ w = L.w + (size_t)r0 * L.cols + c;
+#pragma unroll 8
+        for (int r = r0; r < r1; ++r, w += L.cols) {
+            const float4 w4 = *reinterpret_cast<const float4*>(w);
+            const float u = L.u[r];
+            acc[0] += w4.x * u; acc[1] += w4.y * u; acc[2] += w4.z * u; acc[3] += w4.w * u;
+        }
+        float4 o; o.x = acc[0]; o.y = acc[1]; o.z = acc[2]; o.w = acc[3];
+        *reinterpret_cast<float4*>(L.partial + (size_t)chunk * L.cols + c) = o;
+        return;
+    }
+    for (int r = r0; r < r1; ++r) {
+        const float u = L.u[r];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (c + j < L.cols) acc[j] += L.w[(size_t)r * L.cols + c + j] * u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (c + j < L.cols) L.partial[(size_t)chunk * L.cols + c + j] = acc[j];
 }
 
 __device__ __forceinline__ float block_sum1024(float v, float* red)
@@ -171,7 +189,17 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const mg_sn_layer* __restric
     if (r >= L.rows) return;
     const float* __restrict__ w = L.w + (size_t)r * L.cols;
     float acc = 0.f;
-    for (int c = threadIdx.x & 63; c < L.cols; c += 64) acc += w[c] * L.v[c];
+    if ((L.cols & 3) == 0 && (((uintptr_t)L.w | (uintptr_t)L.v) & 15) == 0) {
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int c = (threadIdx.x & 63) * 4; c < L.cols; c += 256) {
+            const float4 w4 = *reinterpret_cast<const float4*>(w + c), v4 = *reinterpret_cast<const float4*>(L.v + c);
+            a4[0] += w4.x * v4.x; a4[1] += w4.y * v4.y; a4[2] += w4.z * v4.z; a4[3] += w4.w * v4.w;
+        }
+        acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    } else {
+        for (int c = threadIdx.x & 63; c < L.cols; c += 64) acc += w[c] * L.v[c];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if ((threadIdx.x & 63) == 0) L.t2[r] = acc;
@@ -221,7 +249,7 @@ extern "C" int mg_pack_weights(const mg_pack_job* jobs_dev, int32_t njobs, const
 extern "C" int64_t mg_sn_layer_blocks(int32_t rows, int32_t cols, int32_t which)
 {
     if (rows <= 0 || cols <= 0) return -1;
-    if (which == 0) return (int64_t)((cols + 255) / 256) * ((rows + K1_ROWS - 1) / K1_ROWS);      // K1 workgroups
+    if (which == 0) return (int64_t)((cols + K1_COLS - 1) / K1_COLS) * ((rows + K1_ROWS - 1) / K1_ROWS);      // K1 workgroups
     if (which == 1) return (rows + K3_ROWS - 1) / K3_ROWS;                                         // K3 workgroups
     if (which == 2) return (rows + K1_ROWS - 1) / K1_ROWS;                                         // row chunks = rows of `partial`
     return -1;

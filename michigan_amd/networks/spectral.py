@@ -75,8 +75,9 @@ class SpectralPlan:
             k1.append(int(be.mg_sn_layer_blocks(rows, cols, 0)))
             k3.append(int(be.mg_sn_layer_blocks(rows, cols, 1)))
             chunks = int(be.mg_sn_layer_blocks(rows, cols, 2))
-            scratch.append((off, off + cols, off + cols + rows))                    # t1, t2, partial
-            off += cols + rows + chunks * cols
+            c4, r4 = (cols + 3) // 4 * 4, (rows + 3) // 4 * 4                       # every vector starts on a 16-byte boundary
+            scratch.append((off, off + c4, off + c4 + r4))                          # t1, t2, partial
+            off += c4 + r4 + (chunks * cols + 3) // 4 * 4
         self._scratch = torch.empty(off, dtype=torch.float32, device=dev)
         # per-forward buffer layout (floats): [sigma | u_copy | v_copy] per layer, then W_sn, then the images (bytes handled below)
         self._static = dict(layers=layers, k1=k1, k3=k3, scratch=scratch, map1=ops.block_map(k1, dev), map3=ops.block_map(k3, dev))

@@ -98,8 +98,10 @@ class FlatAdam:
     def _build_arena(self):
         dev = self.params[0].device
         self._order = list(reversed(self.params))
-        total = sum(p.numel() for p in self._order)
-        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        # every parameter starts on a 16-byte boundary (a 3-element bias would otherwise misalign everything behind it and keep the
+        # spectral-norm / pack kernels on their 4-byte paths); the padding elements are zeros with zero gradients: Adam leaves them alone
+        total = sum((p.numel() + 3) // 4 * 4 for p in self._order)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -111,7 +113,7 @@ class FlatAdam:
             p.grad = self.flat_grad[off:off + n].view(p.shape)
             p._mg_arena = self
             self._spans.append((off, off + n))
-            off += n
+            off += (n + 3) // 4 * 4
         self._span_of = {id(p): s for p, s in zip(self._order, self._spans)}
 
     def rebind(self):

@@ -76,3 +76,17 @@ hb = [r for r in res if r[1] == "conv" and r[6] > 0 and r[7] / r[6] < 312.5]
 print(f"== conv launches below the ridge: {sum(r[0] for r in hb):.2f} ms/step over {sum(r[2] for r in hb)} launches")
 for t, k, n, ms, tf, desc, gb, gf in hb:
     print(f"  {t:7.3f} ms = {n:3d} x {ms:7.3f} ms  {gb / ms:7.2f} TB/s  AI {gf / gb:5.0f}  {desc}")
+
+# where the launches are furthest from a realistic ceiling: ideal = max(flop / 1.25 PFLOP/s, conv-granular bytes / 5 TB/s)
+lost = []
+for t, kind, n, ms, tf, desc, gb, gf in res:
+    if kind == "wgrad":
+        m = __import__("re").match(r"N(\d+) x(\d+)x(\d+)x(\d+) dy(\d+)x(\d+)x(\d+)", desc)
+        N, H, W, Cc, Hj, Wj, Cg = map(int, m.groups())
+        gb = (N * H * W * Cc + N * Hj * Wj * Cg) * 2 / 1e9
+    ideal = max(gf / 1.25e3, gb / 5.0)              # ms: 1.25 PFLOP/s = 1250 GFLOP/ms, 5 TB/s = 5 GB/ms
+    lost.append(((ms - ideal) * n, n, ms, ideal, kind, desc))
+lost.sort(reverse=True)
+print(f"== time above max(flop / 1.25 PF/s, bytes / 5 TB/s): {sum(l[0] for l in lost):.2f} ms/step")
+for l in lost[:40]:
+    print("  %6.3f ms = %2d x (%6.3f - %6.3f)  %-5s %s" % l)
