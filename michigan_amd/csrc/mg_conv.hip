@@ -22,6 +22,7 @@ int g_mg_conv_halo_big = 1;      // 128 channels x 16x16 pixel halo tiles where 
 int g_mg_conv_halo = 1;          // 3x3 stride-1 convs on the LDS halo-tile kernel (mg_set_option(2, v))
 int g_mg_conv_bigtiles = 1;      // allow the 128x256 / 256x256 tiles (mg_set_option(1, v))
 extern int g_mg_wgrad3x3;          // mg_wgrad.hip (mg_set_option(3, v))
+extern int g_mg_norm_bwd_vec;      // mg_norm.hip (mg_set_option(19, v))
 extern int g_mg_wgrad_min_stages;  // mg_wgrad.hip (mg_set_option(18, v))
 extern int g_mg_conv_thin;         // mg_conv_thin.hip (mg_set_option(6, v))
 extern int g_mg_conv_dot;          // mg_conv_dot.hip (mg_set_option(8, v))
@@ -592,6 +593,7 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 17 && (value == 0 || value == 1)) { g_mg_conv_splitk_wide = value; return MG_OK; }
     if (key == 6 && value >= 0 && value <= 2) { g_mg_conv_thin = value; return MG_OK; }
     if (key == 18 && value >= 1 && value <= 1024) { g_mg_wgrad_min_stages = value; return MG_OK; }
+    if (key == 19 && (value == 0 || value == 1)) { g_mg_norm_bwd_vec = value; return MG_OK; }
     if (key == 7 && (value == 0 || value == 1)) { g_mg_conv_wide = value; return MG_OK; }
     if (key == 8 && value >= 0 && value <= 2) { g_mg_conv_dot = value; return MG_OK; }
     if (key == 9 && (value == 3 || value == 4)) { g_mg_conv_halo_ring = value; return MG_OK; }

@@ -10,6 +10,8 @@
 //   stage 2  fp64 sum over chunks in a fixed order -> sums[g][2][C]
 #include "mg_common.h"
 
+int g_mg_norm_bwd_vec = 1;        // mg_set_option(19, v): 0 = the norm backward reduction stays on the 8-byte quad kernel
+
 namespace {
 
 constexpr int NTHR = 256;
@@ -378,6 +380,83 @@ __global__ __launch_bounds__(NTHR) void stats_stage1_vec(const T* __restrict__ x
     }
 }
 
+// stage 1 of the norm backward reduction (sum dxhat, sum dxhat * xhat, optional d[gamma|beta] output), 16-byte variant of
+// reduce_stage1<T, 1>: a thread keeps VEC channels (mean / rstd loaded once), PIX pixels in flight, every access a full 16-byte
+// vector -- the quad kernel moved its four input streams in 8-byte pieces at 4.4 TB/s and was the largest non-MFMA kernel of the step.
+// Same chunking and partial layout; `act` is NONE / RELU / LRELU only (neg = 1 / 0 / slope), TANH stays on the quad kernel.
+template <typename T, int PIX, bool HAS_H, bool UP>
+__global__ __launch_bounds__(NTHR) void bwd_stage1_vec(const T* __restrict__ x, const T* __restrict__ dh, const T* __restrict__ h, const T* __restrict__ g1,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dgb,
+                                                     float* __restrict__ partial, int64_t P, int C, int64_t chunk, float neg, int H, int W)
+{
+    constexpr int VEC = VT<T>::VEC;
+    __shared__ float red[NTHR * 2 * VEC];
+    const int cv = C / VEC, rows = NTHR / cv;
+    const int tq = threadIdx.x % cv, tr = threadIdx.x / cv;
+    const int g = blockIdx.y, ck = blockIdx.x, nchunks = gridDim.x, c = tq * VEC;
+    const int Cr2 = 2 * ((C + 31) / 32) * 32;
+    const int64_t p0 = (int64_t)ck * chunk;
+    const int64_t p1 = (p0 + chunk < P) ? p0 + chunk : P;
+    float mu[VEC], rs[VEC], s[VEC], ss[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { mu[j] = mean[(size_t)g * C + c + j]; rs[j] = rstd[(size_t)g * C + c + j]; s[j] = 0.f; ss[j] = 0.f; }
+    const size_t base = (size_t)g * P * C + c;
+    const size_t gbase = (size_t)g * P * Cr2 + (size_t)(c >> 5) * 64 + (c & 31);
+    for (int64_t pp = p0 + tr; pp < p1; pp += (int64_t)rows * PIX) {
+        float xv[PIX][VEC], dv[PIX][VEC], hv[PIX][VEC], gv[PIX][VEC];
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) {
+            const int64_t p = pp + (int64_t)k * rows;
+            if (p < p1) {
+                size_t ox = base + (size_t)p * C;
+                if (UP) {                                        // x is the half-resolution source of a nearest 2x upsample (G == 1)
+                    const int q = (int)p, n = q / (H * W), rem = q - n * (H * W);
+                    const int yy = rem / W, xx = rem - yy * W;
+                    ox = ((size_t)(n * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1)) * C + c;
+                }
+                VT<T>::load(x + ox, xv[k]);
+                VT<T>::load(dh + base + (size_t)p * C, dv[k]);
+                if (HAS_H) VT<T>::load(h + base + (size_t)p * C, hv[k]);
+                if (g1) VT<T>::load(g1 + base + (size_t)p * C, gv[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) {
+            const int64_t p = pp + (int64_t)k * rows;
+            if (p < p1) {
+                float dgam[VEC], dbet[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float dpre = HAS_H ? dv[k][j] * act_factor(hv[k][j], neg) : dv[k][j];
+                    const float xh = (xv[k][j] - mu[j]) * rs[j];
+                    const float dxh = g1 ? dpre * gv[k][j] : dpre;
+                    s[j] += dxh; ss[j] += dxh * xh;
+                    dgam[j] = dpre * xh; dbet[j] = dpre;
+                }
+                if (dgb) {
+                    VT<T>::store(dgb + gbase + (size_t)p * Cr2, dgam);
+                    VT<T>::store(dgb + gbase + (size_t)p * Cr2 + 32, dbet);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[threadIdx.x * 2 * VEC + j] = s[j]; red[threadIdx.x * 2 * VEC + VEC + j] = ss[j]; }
+    __syncthreads();
+    if (tr == 0) {
+        float* dst = partial + ((size_t)g * nchunks + ck) * 2 * C;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float a = s[j], b = ss[j];
+            for (int rr = 1; rr < rows; ++rr) {                              // fixed order: deterministic
+                a += red[(threadIdx.x + rr * cv) * 2 * VEC + j];
+                b += red[(threadIdx.x + rr * cv) * 2 * VEC + VEC + j];
+            }
+            dst[c + j] = a; dst[C + c + j] = b;
+        }
+    }
+}
+
 static inline int pix_grid(int64_t P, int rows, int pix, int G)
 {
     int64_t b = (P + (int64_t)rows * pix - 1) / ((int64_t)rows * pix);
@@ -546,6 +625,16 @@ int run_reduce(const void* x, const void* dh, const void* h, const void* g1, con
     dim3 grid(sg.nchunks, G);
     if (MODE == 0 && vec_geom_ok<T>(C))
         hipLaunchKernelGGL((stats_stage1_vec<T, 4>), grid, dim3(NTHR), 0, st, (const T*)x, (float*)partial, P, C, sg.chunk);
+    else if (MODE == 1 && g_mg_norm_bwd_vec && vec_geom_ok<T>(C) && act != MG_ACT_TANH) {
+        // (d[gamma|beta] rows are 32-channel blocks; a thread's VEC channels start at a multiple of VEC and stay inside one block)
+        const float neg = act == MG_ACT_NONE ? 1.f : (act == MG_ACT_RELU ? 0.f : slope);
+        const bool hh = h != nullptr && act != MG_ACT_NONE;
+#define MG_BWD1(HASH, UPF) hipLaunchKernelGGL((bwd_stage1_vec<T, 2, HASH, UPF>), grid, dim3(NTHR), 0, st, (const T*)x, (const T*)dh, (const T*)h, \
+                           (const T*)g1, mean, rstd, (T*)dgb, (float*)partial, P, C, sg.chunk, neg, H, W)
+        if (hh) { if (up) MG_BWD1(true, true); else MG_BWD1(true, false); }
+        else    { if (up) MG_BWD1(false, true); else MG_BWD1(false, false); }
+#undef MG_BWD1
+    }
     else if (MODE == 1 && h == nullptr)
         hipLaunchKernelGGL((reduce_stage1<T, MODE, false>), grid, dim3(NTHR), 0, st,
                            (const T*)x, (const T*)dh, (const T*)h, (const T*)g1, mean, rstd, (T*)dgb,
