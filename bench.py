@@ -128,6 +128,12 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(a))
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a version banner to the C-level stdout when a communicator is created
+    # (flushed at exit, i.e. AFTER anything Python printed), the networks announce themselves ... -- file descriptor 1 is pointed at stderr
+    # for the whole run and the line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -289,7 +295,8 @@ def main():
                 out["cpu_baseline"]["port_vs_real_reference"] = {
                     "port_over_reference_speed": rj["port_over_reference_speed"], "reference_images_per_s": rj["reference"]["images_per_s"],
                     "port_images_per_s": rj["port"]["images_per_s"], "where": rj["what"], "source": "profiles/r03_cpu_reference_vs_port.json"}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 
