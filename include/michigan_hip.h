@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 3
+#define MG_ABI_VERSION 4
 
 enum { MG_F32 = 0, MG_BF16 = 1 };
 enum { MG_ACT_NONE = 0, MG_ACT_RELU = 1, MG_ACT_LRELU = 2, MG_ACT_TANH = 3 };
@@ -59,8 +59,9 @@ enum { MG_OK = 0, MG_ERR_ARG = 1, MG_ERR_LAUNCH = 2, MG_ERR_UNSUPPORTED = 3 };
  *
  * Epilogues
  *   MG_EPI_PLAIN: v = acc + bias[co] (+ resid[n,oy,ox,co]) ; out = act(v)   (bias has Cout_gemm entries);
- *                 if x != NULL: out = (x[n,oy,ox,co] > 0) ? out : 0  -- a data gradient masked by the ReLU whose
- *                 output x the forward conv consumed (saves the separate activation-backward pass)
+ *                 if x != NULL: out = (x[n,oy,ox,co] > 0) ? out : mask_slope * out  -- a data gradient masked by the ReLU
+ *                 (mask_slope 0) / LeakyReLU (its slope) whose output x the forward conv consumed (saves the separate
+ *                 activation-backward pass)
  *   MG_EPI_SPADE: GEMM rows come in blocks of 64 = [32 gamma rows | 32 beta rows]
  *                 of the same 32 output channels (mlp_gamma/mlp_beta fused,
  *                 normalization.py:112-116).  For output channel c:
@@ -94,6 +95,9 @@ typedef struct mg_conv_desc {
                               pixel (y, x) reads source pixel (y >> 1, x >> 1); the upsampled tensor is never materialised */
     int8_t  tap_dy[MG_MAX_TAPS];
     int8_t  tap_dx[MG_MAX_TAPS];
+    float   mask_slope;    /* PLAIN with x != NULL: out = (x > 0) ? out : mask_slope * out.  0 = the ReLU mask; s = the backward of a
+                              LeakyReLU(s) whose OUTPUT x is (only legal when this data gradient is the ONLY gradient of x's producer:
+                              unlike the ReLU mask the leaky one is not idempotent) */
 } mg_conv_desc;
 
 int mg_conv_taps(const mg_conv_desc* d, void* stream);

@@ -15,7 +15,7 @@ MG_F32, MG_BF16 = 0, 1
 MG_ACT_NONE, MG_ACT_RELU, MG_ACT_LRELU, MG_ACT_TANH = 0, 1, 2, 3
 MG_EPI_PLAIN, MG_EPI_SPADE = 0, 1
 MG_MAX_TAPS = 64
-MG_ABI_VERSION = 3
+MG_ABI_VERSION = 4
 
 _i32, _f32, _vp, _i64 = ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
 
@@ -31,6 +31,7 @@ class ConvDesc(ctypes.Structure):
         ("osy", _i32), ("osx", _i32), ("ooy", _i32), ("oox", _i32),
         ("ntaps", _i32), ("epilogue", _i32), ("act", _i32), ("slope", _f32), ("x_up", _i32),
         ("tap_dy", ctypes.c_int8 * MG_MAX_TAPS), ("tap_dx", ctypes.c_int8 * MG_MAX_TAPS),
+        ("mask_slope", _f32),
     ]
 
 

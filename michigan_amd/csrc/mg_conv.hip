@@ -388,7 +388,7 @@ __global__ void conv_splitk_finish(const ConvK d)
         for (int j = 0; j < 4; ++j) v[j] = mg_act(v[j], d.act, d.slope);
         if (Msk) { const f32x4_t mk = ET<T>::load4(Msk + o);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (!(mk[j] > 0.f)) v[j] = 0.f; }
+            for (int j = 0; j < 4; ++j) if (!(mk[j] > 0.f)) v[j] *= d.mslope; }
         ET<T>::store4(Out + o, v);
     }
 }
@@ -563,6 +563,7 @@ extern "C" int mg_conv_taps(const mg_conv_desc* d, void* stream)
     } else {
         MG_CHECK_ARG(d->epilogue == MG_EPI_PLAIN, "mg_conv_taps: bad epilogue %d", d->epilogue);
         MG_CHECK_ARG(d->Cout <= d->Cout_gemm, "mg_conv_taps: Cout > Cout_gemm");
+        MG_CHECK_ARG(d->mask_slope >= 0.f && d->mask_slope <= 1.f, "mg_conv_taps: mask_slope %g outside [0, 1]", (double)d->mask_slope);
     }
     ConvK k;
     k.in = d->in; k.wt = d->wt; k.out = d->out; k.bias = d->bias; k.resid = d->resid; k.x = d->x;
@@ -573,6 +574,7 @@ extern "C" int mg_conv_taps(const mg_conv_desc* d, void* stream)
     k.osy = d->osy; k.osx = d->osx; k.ooy = d->ooy; k.oox = d->oox;
     k.ntaps = d->ntaps; k.act = d->act; k.slope = d->slope;
     k.x_up = d->epilogue == MG_EPI_SPADE ? d->x_up : 0;
+    k.mslope = d->mask_slope;
     k.ngemm = d->N * d->Hj * d->Wj; k.tiles_m = 0; k.tpc = 1; k.tiles_y = k.tiles_x = 0;
     k.ksplit = 1; k.ntiles = 1; k.ws = nullptr;
     k.wide = ((g_mg_conv_wide && d->dtype == MG_BF16 && (d->Cout % 8) == 0) ? 1 : 0) | (g_mg_conv_dbg_noepi ? 2 : 0) | (g_mg_conv_dbg_noepi == 6 ? 4 : 0) | (g_mg_conv_noxpre ? 8 : 0);

@@ -29,6 +29,7 @@ struct ConvK {              // kernel-side view of mg_conv_desc (passed by value
     float* ws;              // split-K: fp32 partial sums [ksplit][ngemm][Cout_gemm]
     int wide;               // bf16 epilogue: lanes l and l+32 exchange quads so that every lane stores 16 contiguous bytes
     int x_up;               // SPADE: x is the half-resolution source of a nearest 2x upsample (read at (y >> 1, x >> 1))
+    float mslope;           // PLAIN with a mask x: masked-off values are multiplied by this (0 = ReLU mask, s = LeakyReLU(s) backward)
 };
 namespace {
 
@@ -259,8 +260,9 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
                                     if constexpr (AUX == 1) t += mg_pk(aux[nt][rq][2 * h2], aux[nt][rq][2 * h2 + 1]);
                                     t = mg_act2<ACT>(t, neg);
                                     if constexpr (AUX == 2) {
-                                        t[0] = aux[nt][rq][2 * h2] > 0.f ? t[0] : 0.f;
-                                        t[1] = aux[nt][rq][2 * h2 + 1] > 0.f ? t[1] : 0.f;
+                                        const mg_pk2 tm = t * d.mslope;
+                                        t[0] = aux[nt][rq][2 * h2] > 0.f ? t[0] : tm[0];
+                                        t[1] = aux[nt][rq][2 * h2 + 1] > 0.f ? t[1] : tm[1];
                                     }
                                     v[rq * 2 + h2] = t;
                                 }
@@ -302,7 +304,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvK& d, f32x16_t (&ac
                         float t = acc[mt][nt][rq * 4 + j] + bias4[rq][j];
                         if (Res) t += rv[rq][j];
                         t = mg_act_fast(t, neg, relu);
-                        v[rq][j] = (Msk && !(mk[rq][j] > 0.f)) ? 0.f : t;
+                        v[rq][j] = (Msk && !(mk[rq][j] > 0.f)) ? t * d.mslope : t;
                     }
                 }
                 bool wide = false;
@@ -507,7 +509,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT
                         for (int j = 0; j < 4; ++j) v[j] = mg_act(v[j], d.act, d.slope);
                         if (Msk) { const f32x4_t mk = ET<T>::load4(Msk + o);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) if (!(mk[j] > 0.f)) v[j] = 0.f; }
+                            for (int j = 0; j < 4; ++j) if (!(mk[j] > 0.f)) v[j] *= d.mslope; }
                         ET<T>::store4(Out + o, v);
                     } else {
 #pragma unroll
@@ -516,7 +518,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& d, f32x16_t (&acc)[MT
                                 float s = v[j];
                                 if (Res) s += ET<T>::load1(Res + o + j);
                                 s = mg_act(s, d.act, d.slope);
-                                if (Msk && !(ET<T>::load1(Msk + o + j) > 0.f)) s = 0.f;
+                                if (Msk && !(ET<T>::load1(Msk + o + j) > 0.f)) s *= d.mslope;
                                 ET<T>::store1(Out + o + j, s);
                             }
                         }

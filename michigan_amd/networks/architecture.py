@@ -48,15 +48,16 @@ class SPADEResnetBlock(nn.Module):
         training mode the upsampled tensor is never built: norm_0 / norm_s read x through the index map (spade_pair)."""
         if self.learned_shortcut and self.training and PAIR_FUSED and ops.spade_pair_supported(x):
             h0, hs = spade_pair(self.norm_0, self.norm_s, x, seg, (ops.ACT_LRELU, ops.ACT_NONE), up=up)
-            dx = self.conv_0(h0)
-            return self.conv_1(self.norm_1(dx, seg, act=ops.ACT_LRELU), resid=self.conv_s(hs))
+            dx = self.conv_0(ops.mark_single_consumer_lrelu(h0))      # h0 / h1 feed exactly one conv each: their LeakyReLU backward
+            h1 = ops.mark_single_consumer_lrelu(self.norm_1(dx, seg, act=ops.ACT_LRELU))      # rides in that conv's data-gradient epilogue
+            return self.conv_1(h1, resid=self.conv_s(hs))
         if up:
             x = ops.upsample2x(x)
         h0, stats = self.norm_0(x, seg, act=ops.ACT_LRELU, return_stats=True)
         shared = stats if self.training else None          # norm_s normalises the same x: reuse the reduction
         x_s = self.conv_s(self.norm_s(x, seg, stats=shared)) if self.learned_shortcut else x
-        dx = self.conv_0(h0)
-        return self.conv_1(self.norm_1(dx, seg, act=ops.ACT_LRELU), resid=x_s)
+        dx = self.conv_0(ops.mark_single_consumer_lrelu(h0))
+        return self.conv_1(ops.mark_single_consumer_lrelu(self.norm_1(dx, seg, act=ops.ACT_LRELU)), resid=x_s)
 
     def shortcut(self, x, seg):
         return self.conv_s(self.norm_s(x, seg)) if self.learned_shortcut else x

@@ -120,7 +120,7 @@ def pad_channels(x: torch.Tensor, mult: int = 8) -> torch.Tensor:
 # ----------------------------------------------------------------------------
 def _launch_conv(inp, wt, out, bias, taps, *, Hj, Wj, isy, isx, osy=1, osx=1, ooy=0, oox=0,
                  cout, cout_gemm, act=ACT_NONE, slope=0.2, resid=None,
-                 spade_x=None, mean=None, rstd=None, gamma_out=None, algo_cin=None, relu_mask=None, x_up=False):
+                 spade_x=None, mean=None, rstd=None, gamma_out=None, algo_cin=None, relu_mask=None, x_up=False, mask_slope=0.0):
     d = C.ConvDesc()
     d.in_, d.wt, d.out = inp.data_ptr(), wt.data_ptr(), out.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
@@ -138,6 +138,7 @@ def _launch_conv(inp, wt, out, bias, taps, *, Hj, Wj, isy, isx, osy=1, osx=1, oo
     d.epilogue = C.MG_EPI_SPADE if spade_x is not None else C.MG_EPI_PLAIN
     d.act, d.slope = act, slope
     d.x_up = 1 if (x_up and spade_x is not None) else 0
+    d.mask_slope = float(mask_slope) if relu_mask is not None else 0.0
     _set_taps(d, taps)
     assert wt.shape[0] == len(taps) and wt.shape[2] == inp.shape[3] and wt.dtype == inp.dtype
     C.backend().mg_conv_taps(d, _stream(inp))
@@ -303,6 +304,27 @@ def unpack_wgrad(dw: torch.Tensor, shape, two: bool = False):
 
 
 FUSE_RELU_MASK = True   # fold a consumed ReLU's backward mask into the data-gradient epilogue (A/B switch)
+FUSE_LRELU_MASK = os.environ.get("MG_FUSE_LRELU_MASK", "1") != "0"    # ... and a single-consumer LeakyReLU's (SPADE outputs inside a residual block)
+MASK_PROTOCOL_CHECK = os.environ.get("MG_MASK_PROTOCOL_CHECK", "0") == "1"
+
+
+def mark_single_consumer_lrelu(t: torch.Tensor, slope: float = 0.2) -> torch.Tensor:
+    """`t` is the output of a fused LeakyReLU(slope) and goes into EXACTLY ONE conv2d: that conv's data gradient may apply the
+    activation's backward mask in its epilogue (mg_conv_desc.mask_slope) and the producer then skips it (no read of `t` in its
+    backward passes).  Do not mark tensors with a second consumer: the gradients would be summed after one of them was masked."""
+    t._mg_lrelu_out = float(slope)
+    return t
+
+
+def _grad_premasked(dh: torch.Tensor, h: torch.Tensor, act: int) -> bool:
+    """True when `dh` (the gradient of the activation output `h`) was already multiplied by the activation's derivative by the
+    consumer's data-gradient epilogue (the record conv_dgrad left for exactly this buffer)."""
+    if act not in (ACT_RELU, ACT_LRELU):
+        return False
+    hit = _RELU_MASKED.pop(dh.data_ptr(), None) == (h.data_ptr(), dh._version)
+    if MASK_PROTOCOL_CHECK and not hit and getattr(h, "_mg_lrelu_out", None) is not None and FUSE_LRELU_MASK:
+        raise RuntimeError("mask protocol: a single-consumer LeakyReLU output received a gradient its consumer did not pre-mask")
+    return hit
 _RELU_MASKED = {}       # address of a ReLU-masked data gradient -> (address of the ReLU output it was masked with, version)
 _DGRAD_CLASSES = {}     # (kh, kw, stride, pad) -> [(py, px, taps, (lo, hi))], tap order of the class-sorted weight image
 _DGRAD_PERM = {}        # (kh, kw, stride, pad, device) -> index tensor that sorts the packed taps by parity class
@@ -329,7 +351,7 @@ def _dgrad_classes(kh: int, kw: int, stride: int, pad: int):
 
 
 def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, kh: int, kw: int, stride: int, pad: int,
-               in_hw: Tuple[int, int], cin: int, relu_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+               in_hw: Tuple[int, int], cin: int, relu_mask: Optional[torch.Tensor] = None, mask_slope: float = 0.0) -> torch.Tensor:
     """Data gradient of a forward conv.  dy is [N, Ho, Wo, Cg8]; wt is the dgrad image
     [taps, roundup(cin,128), Cg8] (pack_weight mode 1).  For stride s the output pixels split into s*s
     parity classes; each class is a stride-1 gather over dy with the subset of taps whose offset is
@@ -354,13 +376,16 @@ def conv_dgrad(dy: torch.Tensor, wt: torch.Tensor, kh: int, kw: int, stride: int
         if hj == 0 or wj == 0 or not taps:
             continue
         _launch_conv(dy, wt[lo:hi], dx, None, taps, Hj=hj, Wj=wj, isy=1, isx=1,
-                     osy=stride, osx=stride, ooy=py, oox=px, cout=cin, cout_gemm=cin, relu_mask=relu_mask)
+                     osy=stride, osx=stride, ooy=py, oox=px, cout=cin, cout_gemm=cin, relu_mask=relu_mask, mask_slope=mask_slope)
     if relu_mask is not None:
         # dx is already multiplied by the ReLU mask of the tensor the forward conv consumed; the producer of that
         # tensor finds the record below and skips its activation-backward pass.  The record is keyed by dx's address
         # and carries its version counter: a gradient that autograd summed out of place lives elsewhere, one it
         # accumulated in place has a bumped version -- in both cases the producer masks again (harmless: idempotent
         # for ReLU), so a skip can only happen for the very buffer this launch wrote.
+        # mask_slope > 0 (LeakyReLU): masking twice is NOT harmless, so only tensors whose producer declared this conv their
+        # single consumer are folded (mark_single_consumer_lrelu) -- then the buffer reaches the producer untouched and the
+        # record is always found (MG_MASK_PROTOCOL_CHECK=1 makes the producer raise if it is not).
         assert relu_mask.shape == dx.shape and relu_mask.dtype == dx.dtype
         _RELU_MASKED[dx.data_ptr()] = (relu_mask.data_ptr(), dx._version)
     return dx
@@ -449,8 +474,9 @@ def act_backward(dy: torch.Tensor, y: torch.Tensor, act: int, slope: float) -> t
 # ----------------------------------------------------------------------------
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, resid, stride, pad, act, slope, x_relu=False, sink=None):
+    def forward(ctx, x, weight, bias, resid, stride, pad, act, slope, x_relu=False, sink=None, x_mask_slope=0.0):
         ctx.sink = sink
+        ctx.x_mask_slope = float(x_mask_slope)
         x = _nhwc(x)
         n, h, w, cx = x.shape
         cout, cin, kh, kw = weight.shape
@@ -488,7 +514,7 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = pack_weight(weight, None, x.dtype, _roundup(cx, 128), dpre8.shape[3], 1)
             dx = conv_dgrad(dpre8, wt, kh, kw, stride, pad, (x.shape[1], x.shape[2]), cx,
-                            relu_mask=x if (ctx.x_relu and FUSE_RELU_MASK) else None)
+                            relu_mask=x if (ctx.x_relu and FUSE_RELU_MASK) else None, mask_slope=ctx.x_mask_slope)
         need_b = has_bias and ctx.needs_input_grad[2]
         slot = None
         if ctx.sink is not None and ctx.needs_input_grad[1] and not _wgrad_swapped(stride, dpre8.shape[3], cx):
@@ -506,7 +532,7 @@ class _Conv2dFn(torch.autograd.Function):
         elif need_b:
             dbias = channel_sums(dpre8)[0, 0, :cout]
         dres = dpre if (has_resid and ctx.needs_input_grad[3]) else None
-        return dx, dw, dbias, dres, None, None, None, None, None, None
+        return dx, dw, dbias, dres, None, None, None, None, None, None, None
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, stride: int = 1,
@@ -520,8 +546,10 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if x.shape[-1] < weight.shape[1]:
         raise ValueError(f"conv2d: input has {x.shape[-1]} channels < weight Cin {weight.shape[1]}")
     xp = pad_channels(x, 8)
-    y = _Conv2dFn.apply(xp, weight, bias, resid, stride, padding, act, slope,
-                        xp is x and getattr(x, "_mg_relu_out", False), _sink_for(weight, bias))
+    fold, mslope = xp is x and getattr(x, "_mg_relu_out", False), 0.0
+    if xp is x and not fold and FUSE_LRELU_MASK and getattr(x, "_mg_lrelu_out", None) is not None:
+        fold, mslope = True, float(x._mg_lrelu_out)             # a LeakyReLU output whose producer named this conv its only consumer
+    y = _Conv2dFn.apply(xp, weight, bias, resid, stride, padding, act, slope, fold, _sink_for(weight, bias), mslope)
     if act == ACT_RELU:
         y._mg_relu_out = True        # consumers may fold this ReLU's backward mask into their data-gradient epilogue
     return y
@@ -815,6 +843,8 @@ class _SpadeFn(torch.autograd.Function):
         dgb = alloc((n, hh, ww, rows), dtype=x.dtype, device=x.device)
         sums = torch.empty((1, 2, c), dtype=torch.float32, device=x.device)
         ws = torch.empty(max(int(be.mg_stats_workspace(1, p, c)), 4), dtype=torch.uint8, device=x.device)
+        if _grad_premasked(dh, h, act):
+            act = ACT_NONE                               # conv_0 / conv_1's data-gradient epilogue already applied the LeakyReLU mask
         hp = _p(h) if act != ACT_NONE else None          # the activation's output is only read for its sign
         be.mg_norm_bwd_reduce(_p(dh), hp, _p(x), _p(g1), _dt(x), 1, p, c, _p(mean), _p(rstd), act, slope,
                               _p(dgb), _p(sums), _p(ws), _stream(x))
@@ -902,6 +932,7 @@ class _SpadePairFn(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
         sums = torch.empty((2, 2, c), dtype=torch.float32, device=x.device)          # [branch][sum dxhat | sum dxhat * xhat][C]
         branches = ((dh0.contiguous(), h0, g10, actv0, wg0, wb0, 1), (dh1.contiguous(), h1, g11, actv1, wg1, wb1, 6))
+        acts = tuple(ACT_NONE if _grad_premasked(br[0], br[1], a) else a for br, a in zip(branches, acts))
         dgbs = []
         for b, (dh, h, g1, actv, wg, wb, base) in enumerate(branches):
             alloc = torch.zeros if rows != 2 * c else torch.empty                      # padded gamma/beta rows must read 0

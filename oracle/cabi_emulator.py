@@ -82,7 +82,7 @@ class EmulatorBackend:
 
     # -- bookkeeping ---------------------------------------------------------
     def mg_abi_version(self):
-        return 3
+        return 4
 
     def mg_wgrad_det_workspace(self, d):
         return 16            # the emulator's weight gradient is a deterministic float64 sum: nothing to size
@@ -113,8 +113,9 @@ class EmulatorBackend:
             if _addr(d.resid):
                 v = v + _view(d.resid, (d.N, d.Hout, d.Wout, d.Cout), td).double()[:, oy, ox]
             v = _act(v, d.act, d.slope)
-            if _addr(d.x):                                   # ReLU-output mask of a data gradient
-                v = v * (_view(d.x, (d.N, d.Hout, d.Wout, d.Cout), td).double()[:, oy, ox] > 0)
+            if _addr(d.x):                                   # ReLU / LeakyReLU-output mask of a data gradient (mask_slope 0 / slope)
+                keep = _view(d.x, (d.N, d.Hout, d.Wout, d.Cout), td).double()[:, oy, ox] > 0
+                v = torch.where(keep, v, v * float(d.mask_slope))
             out[:, oy, ox] = v.to(td)
         else:
             c = d.Cout

@@ -606,6 +606,26 @@ def test_few_output_channel_convs_over_64_channels(case):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("slope", [0.0, 0.2])
+def test_data_gradient_with_folded_activation_mask(dt, slope):
+    """mg_conv_desc.mask_slope: the data gradient of a 3x3 conv multiplied in its epilogue by the backward mask of the ReLU (0) /
+    LeakyReLU (slope) whose output the conv consumed -- halo kernel, ragged sizes -- against the two-step computation."""
+    from michigan_amd import ops
+    tdt = torch.float32 if dt == "f32" else torch.bfloat16
+    g = torch.Generator().manual_seed(int(slope * 10) + 3)
+    n, h, w, cin, cout = 2, 40, 48, 128, 128
+    x = torch.randn(n, h, w, cin, generator=g).to(tdt).cuda()             # the activation output the conv consumed (only its sign matters)
+    dy = torch.randn(n, h, w, cout, generator=g).to(tdt).cuda()
+    wgt = (torch.randn(cout, cin, 3, 3, generator=g) / 24).cuda()
+    wt = ops.pack_weight(wgt, None, tdt, ops._roundup(cin, 128), cout, 1)
+    plain = ops.conv_dgrad(dy, wt, 3, 3, 1, 1, (h, w), cin)
+    masked = ops.conv_dgrad(dy, wt, 3, 3, 1, 1, (h, w), cin, relu_mask=x, mask_slope=slope)
+    ops._RELU_MASKED.pop(masked.data_ptr(), None)
+    want = torch.where(x.float() > 0, plain.float(), plain.float() * slope)
+    _close(f"masked dgrad slope {slope} {dt}", masked, want, 1e-6 if dt == "f32" else TOL["bf16"])
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("C,H,W", [(64, 200, 176), (136, 97, 131)], ids=str)
 def test_spade_halo_ragged_geometry(C, H, W, dt):
     """SPADE epilogue on the halo-tile kernel (chip-filling, ragged tiles and channels): forward and the full backward
