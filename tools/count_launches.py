@@ -1,7 +1,7 @@
 """Launch census of one training step WITHOUT a GPU: torch (aten) ops that would each be a kernel launch on the device, and C-ABI
 calls (= HIP launches), per phase of the step.  Runs the trainer on the contract emulator at a small size -- the launch COUNT of the
 host stack does not depend on the tensor sizes (same code paths), only the dispatch heuristics inside the library do (those are
-counted as one C-ABI call each).     python tools/count_launches.py [--by-op] [--dp]
+counted as one C-ABI call each).     python tools/count_launches.py [--by-op] [--where]
 
 View-like aten ops (no kernel) are not counted; ops issued INSIDE the emulator (its own arithmetic) are not counted either.
 """
@@ -33,6 +33,7 @@ class Census(TorchDispatchMode):
         super().__init__()
         self.phase, self.aten, self.hip, self.depth = "?", Counter(), Counter(), 0
         self.by_op = Counter()
+        self.where = Counter() if "--where" in sys.argv else None
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
@@ -42,6 +43,11 @@ class Census(TorchDispatchMode):
                 # contiguous() / to() of an already matching tensor are no-ops; _to_copy / clone / copy_ are real
                 self.aten[self.phase] += 1
                 self.by_op[(self.phase, name)] += 1
+                if self.where is not None:
+                    import traceback
+                    fr = [f for f in traceback.extract_stack()[:-1] if "/michigan_amd/" in f.filename]
+                    site = "%s:%d" % (fr[-1].filename.split("/michigan_amd/")[-1], fr[-1].lineno) if fr else "<autograd engine / other>"
+                    self.where[(name, site)] += 1
         return out
 
 
@@ -137,6 +143,10 @@ def main():
         ta, th = ta + a, th + h
         print("%-18s %6d %6d" % (p, a, h))
     print("%-18s %6d %6d   total %d launches per G+D step" % ("sum", ta, th, ta + th))
+    if census.where is not None:
+        print("\ntorch launches by innermost michigan_amd frame:")
+        for (name, site), n in sorted(census.where.items(), key=lambda kv: -kv[1])[:60]:
+            print("  %3d x %-22s %s" % (n, name, site))
     if "--by-op" in sys.argv:
         for p in order:
             rows = sorted(((n, op) for (ph, op), n in census.by_op.items() if ph == p), reverse=True)
