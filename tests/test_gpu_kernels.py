@@ -912,9 +912,16 @@ def test_batched_spectral_norm_and_pack_match_contract(dt):
             return outs + [net.c3.weight_u.clone(), net.c1.weight_v.clone(), opt.flat.clone()]
         finally:
             be.mg_sn_power_iteration, be.mg_pack_weights = o1, o2
-    (hip, _), (ref, _) = _both(fn, (x, seg, gy))
+    # ordered split-K sums on the device: behind sign-like Adam updates (lr 1e-3) the last bits of a near-zero gradient decide a
+    # whole weight step, and fp32 atomics would make that -- hence passes 1..3 -- depend on the run
+    prev = ops.WGRAD_DETERMINISTIC
+    ops.set_deterministic(True)
+    try:
+        (hip, _), (ref, _) = _both(fn, (x, seg, gy))
+    finally:
+        ops.set_deterministic(prev)
     for i in range(4):
-        _close(f"batched weights {dt}: output of pass {i}", hip[i], ref[i], 5e-4 if dt == "f32" else 2.0 ** -5)
+        _close(f"batched weights {dt}: output of pass {i}", hip[i], ref[i], (5e-4 if i == 0 else 3e-3) if dt == "f32" else 2.0 ** -5)
     # u, v after three optimiser steps: the weights they were iterated on already differ by a few sign-like Adam updates in bf16
     _close(f"batched weights {dt}: u", hip[4], ref[4], 1e-4 if dt == "f32" else 5e-3)
     _close(f"batched weights {dt}: v", hip[5], ref[5], 1e-4 if dt == "f32" else 5e-3)
