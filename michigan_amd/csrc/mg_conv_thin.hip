@@ -1,4 +1,6 @@
-// mg_conv_thin.hip -- 3x3 / stride-1 / same-size convolutions over an 8-channel bf16 input: the mlp_shared convs
+// mg_conv_thin.hip -- convolutions over an 8-channel bf16 input, forward and weight gradient.  First the 3x3 / stride-1 / same-size
+// case (register-resident weights); further down the kernels for ANY window of at most 7x7 taps at stride 1 or 2 (conv_thin_taps_kernel,
+// wgrad_thin_taps_kernel: weights in LDS, per-workgroup gradient slabs).  The 3x3 case: the mlp_shared convs
 // of every SPADE layer on the (mask, orientation) map (reference normalization.py:94-97,111) and the first
 // convs of the encoders.  K = 9 taps x 8 channels = 72, so these layers are bound by WRITING their output
 // (128 channels per pixel against 8 read): the generic tap-list kernel spent its time in the per-tile ring
