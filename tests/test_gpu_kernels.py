@@ -928,6 +928,43 @@ def test_batched_spectral_norm_and_pack_match_contract(dt):
     assert ((hip[6].cpu() - ref[6]).abs() > 2.5e-3).float().mean() < 0.01       # Adam (lr 1e-3): sign-like updates, see trainer_parity.compare
 
 
+def test_batched_spectral_norm_unaligned_layer():
+    """The power-iteration kernels' 4-byte fallback: a spectral-normed 3x3 conv over 3 input channels (cols = 27: rows of W are not
+    16-byte aligned) next to an aligned one, three training passes (the batched path is live from the second), HIP vs the contract."""
+    import torch.nn as nn
+    from michigan_amd import ops
+    from michigan_amd.networks import spectral
+    from michigan_amd.networks.layers import HipConv2d
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = spectral.spectral_norm(HipConv2d(3, 24, 3, padding=1))
+            self.b = spectral.spectral_norm(HipConv2d(24, 16, 3, padding=1))
+
+        def forward(self, x):
+            spectral.prepare(self)
+            return self.b(self.a(x, act=ops.ACT_LRELU))
+
+    torch.manual_seed(11)
+    sd = {k: v.clone() for k, v in Net().state_dict().items()}
+    x = torch.randn(2, 12, 16, 8, generator=torch.Generator().manual_seed(2))
+    x[..., 3:] = 0
+
+    def fn(x):
+        net = Net().to(x.device)
+        net.load_state_dict(sd)
+        outs = []
+        for _ in range(3):
+            out = net(x)
+            out.float().sum().backward()
+            outs.append(out.detach().float().clone())
+        return outs + [net.a.weight_u.clone(), net.a.weight_v.clone(), net.b.weight_v.clone()]
+    (hip, _), (ref, _) = _both(fn, (x,))
+    for i, (h, r) in enumerate(zip(hip, ref)):
+        _close(f"unaligned spectral layer: value {i}", h, r, 1e-4)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("up", [False, True])
 def test_spade_pair_with_folded_upsample(dt, up):
