@@ -144,3 +144,49 @@ def test_generator_under_inference_mode_and_copy_pickle_after_forward(emulator_b
     with torch.no_grad():
         o2 = call(G2, b)
     assert o2.shape == o1.shape and torch.isfinite(o2).all()
+
+
+def test_folded_leaky_relu_mask_equals_the_two_step_backward(emulator_backend, monkeypatch):
+    """SPADE outputs inside a residual block feed exactly one conv: that conv's data gradient applies the LeakyReLU backward mask in its
+    epilogue (mg_conv_desc.mask_slope) and the SPADE backward skips it.  Generator gradients with the fold on (and the protocol check
+    armed: a marked output whose gradient arrives un-masked raises) equal the gradients with the fold off, and folds really happen."""
+    import copy
+    import random
+    import michigan_amd.model as M
+    from michigan_amd import ops
+    from michigan_amd.synth import synth_batch
+    import parity_utils as PU
+    torch.manual_seed(5)
+    opt = PU.small_opt(ngf=8, ndf=8, crop_size=64, random_expand_mask=False)
+    model_a = M.Pix2PixModel(opt)
+    model_b = copy.deepcopy(model_a)
+    data = synth_batch(2, 64, seed=7)
+    from michigan_amd import _cabi
+    be = _cabi.backend()
+    folded = {"n": 0}
+    orig = be.mg_conv_taps
+
+    def counting(d, stream=None):
+        if d.epilogue == 0 and d.x and d.mask_slope > 0:
+            folded["n"] += 1
+        return orig(d, stream)
+    monkeypatch.setattr(be, "mg_conv_taps", counting, raising=False)
+    monkeypatch.setattr(ops, "MASK_PROTOCOL_CHECK", True)
+    grads = {}
+    for name, model, fold in (("fold", model_a, True), ("plain", model_b, False)):
+        monkeypatch.setattr(ops, "FUSE_LRELU_MASK", fold)
+        random.seed(2)
+        d = model.preprocess_input(data)
+        fake = model.generate_fake(d)
+        fake.float().square().mean().backward()
+        grads[name] = {k: p.grad.detach().clone() for k, p in model.netG.named_parameters() if p.grad is not None}
+        if fold:
+            assert folded["n"] >= 14, folded                   # norm_0 and norm_1 of the seven residual blocks
+            n_fold = folded["n"]
+        else:
+            assert folded["n"] == n_fold                       # nothing folded with the switch off
+    assert grads["fold"].keys() == grads["plain"].keys() and len(grads["fold"]) > 50
+    gmax = max(h.abs().max().item() for h in grads["plain"].values())
+    for k, g in grads["fold"].items():
+        h = grads["plain"][k]                                  # (biases in front of an instance norm have zero gradient: pure rounding noise)
+        assert (g - h).abs().max().item() <= 1e-6 * max(h.abs().max().item(), 1e-3 * gmax), k
