@@ -3,7 +3,7 @@
 set -u
 TAG=${1:-k}; PAT=${2:-.}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/kstats_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o p -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/bench.json 2> $OUT/prof.log
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o p -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline ${KSTATS_ARGS:-} > $OUT/bench.json 2> $OUT/prof.log
 F=$(ls $OUT/prof/*kernel_stats.csv | head -1); cp "$F" $OUT/kernel_stats.csv; rm -rf $OUT/prof
 python - <<PY
 import csv, re
