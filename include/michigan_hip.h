@@ -138,7 +138,9 @@ int64_t mg_wgrad_det_workspace(const mg_wgrad_desc* d);
 
 /* ---------------------------------------------------------------------------
  * Per-channel statistics (sync-BN / instance-norm reduce).
- *   x is [G][P][C]; sums[g][0][c] = sum_p x, sums[g][1][c] = sum_p x*x  (fp32).
+ *   x is [G][P][C]; sums[g][0][c] = sum_p x, sums[g][1][c] = sum_p x*x  (fp64: the reduction accumulates the
+ *   shifted values x - x[g][0][c] in fp32 per thread, adds the partial sums in fp64 and un-shifts in fp64, so that
+ *   var = E[x^2] - E[x]^2 in mg_norm_finalize carries no fp32 cancellation; the cross-rank all-reduce adds fp64 sums).
  *   G = 1, P = N*H*W for batch norm (sync_batchnorm/batchnorm.py:63-68,128-145:
  *   F.batch_norm on one device, sum/ssum reduce on several); G = N, P = H*W for
  *   nn.InstanceNorm2d (normalization.py:47-48, encoder.py:173-181).
@@ -147,20 +149,20 @@ int64_t mg_wgrad_det_workspace(const mg_wgrad_desc* d);
  * ------------------------------------------------------------------------- */
 int64_t mg_stats_workspace(int32_t G, int64_t P, int32_t C);
 int mg_channel_stats(const void* x, int32_t dtype, int32_t G, int64_t P, int32_t C,
-                     float* sums /* [G][2][C] */, void* partial, void* stream);
+                     double* sums /* [G][2][C] */, void* partial, void* stream);
 /* mg_channel_stats followed by mg_norm_finalize in TWO launches instead of three (stage 2 finalizes): for statistics that need no
  * cross-rank reduction in between (instance norm; batch norm on one GPU).  sums are multiplied by sum_scale before use (4 for the
  * statistics of a nearest 2x upsample taken from its source, `count` then counts the upsampled elements).  Bit-identical to
  * mg_channel_stats + (sums *= sum_scale) + mg_norm_finalize. */
 int mg_channel_stats_finalize(const void* x, int32_t dtype, int32_t G, int64_t P, int32_t C, float sum_scale, double count,
                               float eps, float momentum, float* running_mean, float* running_var,
-                              float* sums, float* mean, float* rstd, void* partial, void* stream);
+                              double* sums, float* mean, float* rstd, void* partial, void* stream);
 
 /* sums[G][2][C] + element count -> mean[G][C], rstd[G][C] = 1/sqrt(biased_var + eps) (fp64 inside); when
  * running_mean/var are given (G == 1) they are updated with momentum and the UNBIASED variance, as
  * F.batch_norm does (sync_batchnorm/batchnorm.py:65-68,136-143).  `count` is the global element count
  * (after the cross-rank all-reduce of `sums`). */
-int mg_norm_finalize(const float* sums, int32_t G, int32_t C, double count, float eps, float momentum,
+int mg_norm_finalize(const double* sums, int32_t G, int32_t C, double count, float eps, float momentum,
                      float* running_mean, float* running_var, float* mean, float* rstd, void* stream);
 
 /* y = act((x - mean[g][c]) * rstd[g][c])   (InstanceNorm2d + LeakyReLU,

@@ -8,6 +8,11 @@
 //   stage 1  grid (chunks, G): register accumulation over the block's pixel
 //            chunk, LDS tree across the thread rows -> partial[g][chunk][2][C]
 //   stage 2  fp64 sum over chunks in a fixed order -> sums[g][2][C]
+// Forward statistics (sum x, sum x^2) are conditioned like a two-pass variance: stage 1 accumulates the SHIFTED values
+// x - k[g][c] with the pivot k = x[g][pixel 0][c] (a sample of the channel, so sum (x-k)^2 ~ n (var + (mean-k)^2) carries no
+// mean^2 / var cancellation into the fp32 partials), stage 2 adds the partials in fp64, un-shifts in fp64
+// (sum x = s + n k, sum x^2 = ss + 2 k s + n k^2) and hands fp64 sums to the cross-rank all-reduce and to finalize: nothing
+// between the per-thread partials and var = E[x^2] - E[x]^2 is rounded to fp32 (the one-pass fp32 sums were).
 #include "mg_common.h"
 
 int g_mg_norm_bwd_vec = 1;        // mg_set_option(19, v): 0 = the norm backward reduction stays on the 8-byte quad kernel
@@ -61,6 +66,8 @@ __global__ __launch_bounds__(NTHR) void reduce_stage1(
         const int c = (qd < c4 ? qd : 0) * 4;
         float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
         f32x4_t mu, rs;
+        f32x4_t kv = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == 0) kv = ET<T>::load4(x + (size_t)g * P * C + c);     // pivot of the shifted sums: the group's first pixel
         if (MODE == 1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { mu[j] = mean[(size_t)g * C + c + j]; rs[j] = rstd[(size_t)g * C + c + j]; }
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(NTHR) void reduce_stage1(
                 const f32x4_t xv = ET<T>::load4(x + ox);
                 if (MODE == 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { s[j] += xv[j]; ss[j] += xv[j] * xv[j]; }
+                    for (int j = 0; j < 4; ++j) { const float t = xv[j] - kv[j]; s[j] += t; ss[j] += t * t; }
                 } else {
                     const f32x4_t dv = ET<T>::load4(dh + o);
                     f32x4_t hv = {1.f, 1.f, 1.f, 1.f};              // h only matters through the sign of the activation's output
@@ -343,10 +350,11 @@ __global__ __launch_bounds__(NTHR) void stats_stage1_vec(const T* __restrict__ x
     const int g = blockIdx.y, ck = blockIdx.x, nchunks = gridDim.x, c = tq * VEC;
     const int64_t p0 = (int64_t)ck * chunk;
     const int64_t p1 = (p0 + chunk < P) ? p0 + chunk : P;
-    float s[VEC], ss[VEC];
+    float s[VEC], ss[VEC], kv[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { s[j] = 0.f; ss[j] = 0.f; }
     const size_t base = (size_t)g * P * C + c;
+    VT<T>::load(x + base, kv);                                           // pivot of the shifted sums: the group's first pixel
     for (int64_t pp = p0 + tr; pp < p1; pp += (int64_t)rows * PIX) {
         float xv[PIX][VEC];
 #pragma unroll
@@ -355,13 +363,13 @@ __global__ __launch_bounds__(NTHR) void stats_stage1_vec(const T* __restrict__ x
             if (p < p1) VT<T>::load(x + base + (size_t)p * C, xv[k]);
             else {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) xv[k][j] = 0.f;
+                for (int j = 0; j < VEC; ++j) xv[k][j] = kv[j];           // contributes (k - k) = 0
             }
         }
 #pragma unroll
         for (int k = 0; k < PIX; ++k)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) { s[j] += xv[k][j]; ss[j] += xv[k][j] * xv[k][j]; }
+            for (int j = 0; j < VEC; ++j) { const float t = xv[k][j] - kv[j]; s[j] += t; ss[j] += t * t; }
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { red[threadIdx.x * 2 * VEC + j] = s[j]; red[threadIdx.x * 2 * VEC + VEC + j] = ss[j]; }
@@ -467,7 +475,7 @@ static inline int pix_grid(int64_t P, int rows, int pix, int G)
 
 // sums[g][2][C] (+ element count) -> mean / rstd (fp64 inside), optional running-statistics update (G == 1):
 // replaces a dozen [C]-sized eager ops per normalisation layer.
-__global__ void norm_finalize_kernel(const float* __restrict__ sums, int G, int C, double count, float eps, float momentum,
+__global__ void norm_finalize_kernel(const double* __restrict__ sums, int G, int C, double count, float eps, float momentum,
                                      float* __restrict__ running_mean, float* __restrict__ running_var,
                                      float* __restrict__ mean, float* __restrict__ rstd)
 {
@@ -562,17 +570,19 @@ __global__ __launch_bounds__(NTHR) void norm_bwd_apply2_vec(const mg_norm_apply2
     }
 }
 
-// stage 2 + finalize in one launch (no cross-rank reduction between them: instance norm, single-GPU batch norm): a block owns 16
-// channels; lanes 0..15 of each thread row sum the channels' partial sums, lanes 16..31 their partial sums of squares (fp64, fixed
-// order: the same values reduce_stage2 produces), then lanes 0..15 run norm_finalize_kernel's arithmetic on the fp32-rounded sums --
-// bit-identical to the two-launch path.  sum_scale: the statistics of a nearest 2x upsample from its source (x 4, exact).
-__global__ __launch_bounds__(256) void reduce_stage2_finalize(const float* __restrict__ partial, float* __restrict__ sums, int nchunks, int C,
-                                                              float sum_scale, double count, float eps, float momentum,
-                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                              float* __restrict__ mean, float* __restrict__ rstd)
+// Stage 2 of the forward statistics: a block owns 16 channels; lanes 0..15 of each thread row sum the channels' shifted partial sums,
+// lanes 16..31 their shifted partial sums of squares (fp64, fixed order), then lanes 0..15 un-shift with the pivot x[g][0][c] in fp64
+// and write sums[g][2][C] (fp64; x sum_scale: the statistics of a nearest 2x upsample from its source, x 4, exact).
+// FIN: the same lanes also run norm_finalize_kernel's arithmetic on those fp64 sums -- statistics that need no cross-rank reduction in
+// between (instance norm; batch norm on one GPU) finish in two launches, bit-identical to mg_channel_stats + mg_norm_finalize.
+template <typename T, bool FIN>
+__global__ __launch_bounds__(256) void stats_stage2(const float* __restrict__ partial, const T* __restrict__ x, int64_t P, double* __restrict__ sums,
+                                                    int nchunks, int C, double sum_scale, double count, float eps, float momentum,
+                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                    float* __restrict__ mean, float* __restrict__ rstd)
 {
     __shared__ double red[256];
-    __shared__ float fin[32];
+    __shared__ double fin[32];
     const int cl = threadIdx.x & 31, kk = threadIdx.x >> 5;
     const int c = blockIdx.x * 16 + (cl & 15);
     const int g = blockIdx.y;
@@ -581,6 +591,8 @@ __global__ __launch_bounds__(256) void reduce_stage2_finalize(const float* __res
     double a = 0.0;
     if (c < C) {
         const float* p = partial + (size_t)g * nchunks * C2 + i;
+        // eight independent loads in flight per thread (the trip count is a runtime value: without the explicit batch the loop was a
+        // chain of ~64 dependent L2 round trips)
         int k = kk;
         for (; k + 56 < nchunks; k += 64) {
             float v[8];
@@ -596,36 +608,60 @@ __global__ __launch_bounds__(256) void reduce_stage2_finalize(const float* __res
     if (kk == 0) {
 #pragma unroll
         for (int r = 1; r < 8; ++r) a += red[r * 32 + cl];
-        const float f = (float)a * sum_scale;
-        fin[cl] = f;
-        if (c < C) sums[(size_t)g * C2 + i] = f;
+        fin[cl] = a;
     }
     __syncthreads();
     if (threadIdx.x < 16 && c < C) {
-        const double s = fin[threadIdx.x], ss = fin[16 + threadIdx.x];
-        const double m = s / count;
-        double var = ss / count - m * m;
-        if (var < 0.0) var = 0.0;
-        mean[(size_t)g * C + c] = (float)m;
-        rstd[(size_t)g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (running_mean) {
-            const double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        const double kv = (double)ET<T>::load1(x + (size_t)g * P * C + c);
+        const double sh = fin[threadIdx.x], ssh = fin[16 + threadIdx.x], n = (double)P;
+        const double s = (sh + n * kv) * sum_scale;
+        const double ss = (ssh + 2.0 * kv * sh + n * kv * kv) * sum_scale;
+        sums[(size_t)g * C2 + c] = s;
+        sums[(size_t)g * C2 + C + c] = ss;
+        if (FIN) {
+            const double m = s / count;
+            double var = ss / count - m * m;
+            if (var < 0.0) var = 0.0;
+            mean[(size_t)g * C + c] = (float)m;
+            rstd[(size_t)g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (running_mean) {
+                const double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
         }
     }
 }
 
-template <typename T, int MODE>
+// forward statistics: stage 1 (shifted partial sums) + stage 2 (fp64 sums [+ finalize])
+template <typename T, bool FIN>
+int run_stats(const void* x, int G, int64_t P, int C, double* sums, void* partial, double sum_scale, double count, float eps, float momentum,
+              float* running_mean, float* running_var, float* mean, float* rstd, hipStream_t st)
+{
+    const StatGeom sg = stat_geom(G, P, C);
+    dim3 grid(sg.nchunks, G);
+    if (vec_geom_ok<T>(C))
+        hipLaunchKernelGGL((stats_stage1_vec<T, 4>), grid, dim3(NTHR), 0, st, (const T*)x, (float*)partial, P, C, sg.chunk);
+    else
+        hipLaunchKernelGGL((reduce_stage1<T, 0, true>), grid, dim3(NTHR), 0, st, (const T*)x, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (T*)nullptr, (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, 0, 0.f, 0, 0, 0);
+    MG_CHECK_LAUNCH("channel statistics (stage 1)");
+    hipLaunchKernelGGL((stats_stage2<T, FIN>), dim3((C + 15) / 16, G), dim3(256), 0, st, (const float*)partial, (const T*)x, P, sums, sg.nchunks, C,
+                       sum_scale, count, eps, momentum, running_mean, running_var, mean, rstd);
+    MG_CHECK_LAUNCH("channel statistics (stage 2)");
+    return MG_OK;
+}
+
+// norm backward reduction (sum dxhat, sum dxhat * xhat [+ d[gamma|beta]]): these sums cancel by themselves (no pivot helps);
+// fp32 per-thread partials over >= 16 values, fp64 across chunks.
+template <typename T>
 int run_reduce(const void* x, const void* dh, const void* h, const void* g1, const float* mean, const float* rstd,
                void* dgb, int G, int64_t P, int C, float* sums, void* partial, int act, float slope, hipStream_t st,
                int up = 0, int H = 0, int W = 0)
 {
     const StatGeom sg = stat_geom(G, P, C);
     dim3 grid(sg.nchunks, G);
-    if (MODE == 0 && vec_geom_ok<T>(C))
-        hipLaunchKernelGGL((stats_stage1_vec<T, 4>), grid, dim3(NTHR), 0, st, (const T*)x, (float*)partial, P, C, sg.chunk);
-    else if (MODE == 1 && g_mg_norm_bwd_vec && vec_geom_ok<T>(C) && act != MG_ACT_TANH) {
+    if (g_mg_norm_bwd_vec && vec_geom_ok<T>(C) && act != MG_ACT_TANH) {
         // (d[gamma|beta] rows are 32-channel blocks; a thread's VEC channels start at a multiple of VEC and stay inside one block)
         const float neg = act == MG_ACT_NONE ? 1.f : (act == MG_ACT_RELU ? 0.f : slope);
         const bool hh = h != nullptr && act != MG_ACT_NONE;
@@ -635,12 +671,12 @@ int run_reduce(const void* x, const void* dh, const void* h, const void* g1, con
         else    { if (up) MG_BWD1(false, true); else MG_BWD1(false, false); }
 #undef MG_BWD1
     }
-    else if (MODE == 1 && h == nullptr)
-        hipLaunchKernelGGL((reduce_stage1<T, MODE, false>), grid, dim3(NTHR), 0, st,
+    else if (h == nullptr)
+        hipLaunchKernelGGL((reduce_stage1<T, 1, false>), grid, dim3(NTHR), 0, st,
                            (const T*)x, (const T*)dh, (const T*)h, (const T*)g1, mean, rstd, (T*)dgb,
                            (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, act, slope, up, H, W);
     else
-        hipLaunchKernelGGL((reduce_stage1<T, MODE, true>), grid, dim3(NTHR), 0, st,
+        hipLaunchKernelGGL((reduce_stage1<T, 1, true>), grid, dim3(NTHR), 0, st,
                            (const T*)x, (const T*)dh, (const T*)h, (const T*)g1, mean, rstd, (T*)dgb,
                            (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, act, slope, up, H, W);
     MG_CHECK_LAUNCH("reduce_stage1");
@@ -664,19 +700,19 @@ extern "C" int64_t mg_stats_workspace(int32_t G, int64_t P, int32_t C)
 }
 
 extern "C" int mg_channel_stats(const void* x, int32_t dtype, int32_t G, int64_t P, int32_t C,
-                                float* sums, void* partial, void* stream)
+                                double* sums, void* partial, void* stream)
 {
     MG_CHECK_NORM_GEOM("mg_channel_stats");
     MG_CHECK_ARG(x && sums && partial, "mg_channel_stats: null pointer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MG_BF16)
-        return run_reduce<uint16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, G, P, C, sums, partial, 0, 0.f, st);
-    return run_reduce<float, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, G, P, C, sums, partial, 0, 0.f, st);
+        return run_stats<uint16_t, false>(x, G, P, C, sums, partial, 1.0, 1.0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, st);
+    return run_stats<float, false>(x, G, P, C, sums, partial, 1.0, 1.0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, st);
 }
 
 extern "C" int mg_channel_stats_finalize(const void* x, int32_t dtype, int32_t G, int64_t P, int32_t C, float sum_scale, double count,
                                          float eps, float momentum, float* running_mean, float* running_var,
-                                         float* sums, float* mean, float* rstd, void* partial, void* stream)
+                                         double* sums, float* mean, float* rstd, void* partial, void* stream)
 {
     MG_CHECK_NORM_GEOM("mg_channel_stats_finalize");
     MG_CHECK_ARG(x && sums && mean && rstd && partial, "mg_channel_stats_finalize: null pointer");
@@ -684,22 +720,9 @@ extern "C" int mg_channel_stats_finalize(const void* x, int32_t dtype, int32_t G
     MG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr) && (running_mean == nullptr || G == 1),
                  "mg_channel_stats_finalize: running statistics need both buffers and G == 1");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const StatGeom sg = stat_geom(G, P, C);
-    dim3 grid(sg.nchunks, G);
-    if (dtype == MG_BF16) {
-        if (vec_geom_ok<uint16_t>(C)) hipLaunchKernelGGL((stats_stage1_vec<uint16_t, 4>), grid, dim3(NTHR), 0, st, (const uint16_t*)x, (float*)partial, P, C, sg.chunk);
-        else hipLaunchKernelGGL((reduce_stage1<uint16_t, 0, true>), grid, dim3(NTHR), 0, st, (const uint16_t*)x, (const uint16_t*)nullptr, (const uint16_t*)nullptr,
-                                (const uint16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (uint16_t*)nullptr, (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, 0, 0.f, 0, 0, 0);
-    } else {
-        if (vec_geom_ok<float>(C)) hipLaunchKernelGGL((stats_stage1_vec<float, 4>), grid, dim3(NTHR), 0, st, (const float*)x, (float*)partial, P, C, sg.chunk);
-        else hipLaunchKernelGGL((reduce_stage1<float, 0, true>), grid, dim3(NTHR), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr,
-                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, 0, 0.f, 0, 0, 0);
-    }
-    MG_CHECK_LAUNCH("mg_channel_stats_finalize(stage 1)");
-    hipLaunchKernelGGL(reduce_stage2_finalize, dim3((C + 15) / 16, G), dim3(256), 0, st, (const float*)partial, sums, sg.nchunks, C, sum_scale, count,
-                       eps, momentum, running_mean, running_var, mean, rstd);
-    MG_CHECK_LAUNCH("mg_channel_stats_finalize(stage 2)");
-    return MG_OK;
+    if (dtype == MG_BF16)
+        return run_stats<uint16_t, true>(x, G, P, C, sums, partial, (double)sum_scale, count, eps, momentum, running_mean, running_var, mean, rstd, st);
+    return run_stats<float, true>(x, G, P, C, sums, partial, (double)sum_scale, count, eps, momentum, running_mean, running_var, mean, rstd, st);
 }
 
 extern "C" int mg_norm_act_fwd(const void* x, void* y, int32_t dtype, int32_t G, int64_t P, int32_t C,
@@ -744,8 +767,8 @@ extern "C" int mg_norm_bwd_reduce(const void* dh, const void* h, const void* x, 
     MG_CHECK_ARG(dgb == nullptr || G == 1, "mg_norm_bwd_reduce: dgb output requires G == 1");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MG_BF16)
-        return run_reduce<uint16_t, 1>(x, dh, h, g1, mean, rstd, dgb, G, P, C, sums, partial, act, slope, st);
-    return run_reduce<float, 1>(x, dh, h, g1, mean, rstd, dgb, G, P, C, sums, partial, act, slope, st);
+        return run_reduce<uint16_t>(x, dh, h, g1, mean, rstd, dgb, G, P, C, sums, partial, act, slope, st);
+    return run_reduce<float>(x, dh, h, g1, mean, rstd, dgb, G, P, C, sums, partial, act, slope, st);
 }
 
 extern "C" int mg_norm_bwd_reduce_up(const void* dh, const void* h, const void* x, const void* g1,
@@ -759,8 +782,8 @@ extern "C" int mg_norm_bwd_reduce_up(const void* dh, const void* h, const void* 
     MG_CHECK_ARG(N > 0 && H > 0 && W > 0 && (H % 2) == 0 && (W % 2) == 0 && P < (1L << 31), "mg_norm_bwd_reduce_up: H, W must be even");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MG_BF16)
-        return run_reduce<uint16_t, 1>(x, dh, h, g1, mean, rstd, dgb, G, P, C, sums, partial, act, slope, st, 1, H, W);
-    return run_reduce<float, 1>(x, dh, h, g1, mean, rstd, dgb, G, P, C, sums, partial, act, slope, st, 1, H, W);
+        return run_reduce<uint16_t>(x, dh, h, g1, mean, rstd, dgb, G, P, C, sums, partial, act, slope, st, 1, H, W);
+    return run_reduce<float>(x, dh, h, g1, mean, rstd, dgb, G, P, C, sums, partial, act, slope, st, 1, H, W);
 }
 
 template <typename T>
@@ -844,7 +867,7 @@ extern "C" int mg_norm_bwd_apply(const void* dh, const void* h, const void* x, c
     return MG_OK;
 }
 
-extern "C" int mg_norm_finalize(const float* sums, int32_t G, int32_t C, double count, float eps, float momentum,
+extern "C" int mg_norm_finalize(const double* sums, int32_t G, int32_t C, double count, float eps, float momentum,
                                 float* running_mean, float* running_var, float* mean, float* rstd, void* stream)
 {
     MG_CHECK_ARG(sums && mean && rstd, "mg_norm_finalize: null pointer");

@@ -405,7 +405,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int,
         # the roles of x and dy swapped, whose tiny "Cin" takes the packed-taps path; transpose the small result.
         swapped = _wgrad_launch(dy, x, [(pad - ky, pad - kx) for ky in range(kh) for kx in range(kw)], 1, False)
         dw = swapped.transpose(1, 2).contiguous()
-        return (dw, channel_sums(dy)[0, 0].contiguous()) if want_bias else dw
+        return (dw, channel_sums(dy)[0, 0].float()) if want_bias else dw
     return _wgrad_launch(x, dy, fwd_taps(kh, kw, pad), stride, want_bias)
 
 
@@ -448,12 +448,13 @@ def _wgrad_launch(x, dy, taps, stride, want_bias, out=None):
 
 
 def channel_sums(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
-    """x viewed as [G, P, C] -> fp32 [G, 2, C] (sum, sum of squares); deterministic two-stage reduce."""
+    """x viewed as [G, P, C] -> fp64 [G, 2, C] (sum, sum of squares); deterministic two-stage reduce (shifted fp32 partial sums,
+    fp64 across chunks: mg_norm.hip)."""
     c = x.shape[-1]
     p = x.numel() // (groups * c)
     be = C.backend()
     ws = torch.empty(max(int(be.mg_stats_workspace(groups, p, c)), 4), dtype=torch.uint8, device=x.device)
-    sums = torch.empty((groups, 2, c), dtype=torch.float32, device=x.device)
+    sums = torch.empty((groups, 2, c), dtype=torch.float64, device=x.device)
     be.mg_channel_stats(_p(x), _dt(x), groups, p, c, _p(sums), _p(ws), _stream(x))
     return sums
 
@@ -530,7 +531,7 @@ class _Conv2dFn(torch.autograd.Function):
                 dbias = res[1][:cout]
             dw = unpack_wgrad(res[0] if need_b else res, weight.shape)
         elif need_b:
-            dbias = channel_sums(dpre8)[0, 0, :cout]
+            dbias = channel_sums(dpre8)[0, 0, :cout].float()
         dres = dpre if (has_resid and ctx.needs_input_grad[3]) else None
         return dx, dw, dbias, dres, None, None, None, None, None, None, None
 
@@ -654,7 +655,7 @@ def stats_finalize(x: torch.Tensor, groups: int, count: float, eps: float, momen
     p = x.numel() // (groups * c)
     be = C.backend()
     ws = torch.empty(max(int(be.mg_stats_workspace(groups, p, c)), 4), dtype=torch.uint8, device=x.device)
-    sums = torch.empty((groups, 2, c), dtype=torch.float32, device=x.device)
+    sums = torch.empty((groups, 2, c), dtype=torch.float64, device=x.device)
     mean = torch.empty((groups, c), dtype=torch.float32, device=x.device)
     rstd = torch.empty((groups, c), dtype=torch.float32, device=x.device)
     be.mg_channel_stats_finalize(_p(x), _dt(x), groups, p, c, float(sum_scale), float(count), eps, momentum, _p(running_mean), _p(running_var),
@@ -874,7 +875,7 @@ class _SpadeFn(torch.autograd.Function):
             dwg, dwb = unpack_wgrad(res[0] if need_b else res, w_gamma.shape, two=True)
             db = res[1] if need_b else None
         elif need_b:
-            db = channel_sums(dgb)[0, 0]
+            db = channel_sums(dgb)[0, 0].float()
         if ctx.needs_input_grad[0]:
             if work is not None:
                 work.wait()
@@ -972,7 +973,7 @@ class _SpadePairFn(torch.autograd.Function):
                 grads[base + 1], grads[base + 3] = unpack_wgrad(res[0] if need_b else res, wg.shape, two=True)
                 db = res[1] if need_b else None
             elif need_b:
-                db = channel_sums(dgbs[b])[0, 0]
+                db = channel_sums(dgbs[b])[0, 0].float()
             if db is not None:
                 db = db.reshape(rows // 64, 2, 32)
                 grads[base + 2], grads[base + 4] = db[:, 0].reshape(-1)[:c], db[:, 1].reshape(-1)[:c]

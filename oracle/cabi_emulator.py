@@ -154,19 +154,19 @@ class EmulatorBackend:
 
     def mg_channel_stats(self, x, dtype, G, P, C, sums, partial, stream=None):
         xv = _view(x, (G, P, C), _TD[dtype]).double()
-        s = _view(sums, (G, 2, C), torch.float32)
-        s[:, 0] = xv.sum(1).float()
-        s[:, 1] = (xv * xv).sum(1).float()
+        s = _view(sums, (G, 2, C), torch.float64)
+        s[:, 0] = xv.sum(1)
+        s[:, 1] = (xv * xv).sum(1)
         return 0
 
     def mg_channel_stats_finalize(self, x, dtype, G, P, C, sum_scale, count, eps, momentum, running_mean, running_var, sums, mean, rstd,
                                   partial, stream=None):
         self.mg_channel_stats(x, dtype, G, P, C, sums, partial)
-        _view(sums, (G, 2, C), torch.float32).mul_(sum_scale)
+        _view(sums, (G, 2, C), torch.float64).mul_(sum_scale)
         return self.mg_norm_finalize(sums, G, C, count, eps, momentum, running_mean, running_var, mean, rstd)
 
     def mg_norm_finalize(self, sums, G, C, count, eps, momentum, running_mean, running_var, mean, rstd, stream=None):
-        s = _view(sums, (G, 2, C), torch.float32).double()
+        s = _view(sums, (G, 2, C), torch.float64)
         m = s[:, 0] / count
         var = (s[:, 1] / count - m * m).clamp_min(0)
         _view(mean, (G, C), torch.float32)[:] = m.float()

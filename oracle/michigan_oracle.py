@@ -208,7 +208,7 @@ def spadeb_generator(sd: SD, opt, input_ref, orient_mask, image_ref, input_tag, 
         x = up(x)
     x = tap("G_middle_1", spade_resblock(x, seg, sd, "G_middle_1.", training, updates))
     for i in range(4):
-        x = spade_resblock(up(x), seg, sd, f"up_{i}.", training, updates)
+        x = tap(f"up_{i}_block", spade_resblock(up(x), seg, sd, f"up_{i}.", training, updates))
         x = tap(f"up_{i}", back_feats[i] * (1 - hair_masks[i]) + x * (1 - back_masks[i]))
     x = F.conv2d(F.leaky_relu(x, 0.2), sd["conv_img.weight"], sd["conv_img.bias"], padding=1)
     return torch.tanh(x)
