@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 4
+#define MG_ABI_VERSION 5
 
 enum { MG_F32 = 0, MG_BF16 = 1 };
 enum { MG_ACT_NONE = 0, MG_ACT_RELU = 1, MG_ACT_LRELU = 2, MG_ACT_TANH = 3 };
@@ -340,6 +340,19 @@ int mg_gabor_argmax_fwd(const void* img, const float* bank, float* conf, uint8_t
                         int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int mg_gabor_argmax_bwd(const float* dconf, const uint8_t* idx, const float* bank, void* dimg, int32_t dtype,
                         int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Self-attention of the frozen orientation in-painting net (generator.py:467-485, SelfAttention.forward):
+ *     out[n][i][:] = sum_j softmax_j( q[n][i][:] . k[n][j][:] ) * v[n][j][:]        i, j = 0 .. L-1 (L = H*W positions),
+ * no 1/sqrt(d) scale (the reference has none).  q, k: [N][L][d_qk], v: [N][L][d_v], out: [N][L][d_v], all position-major
+ * (= NHWC with H*W flattened) in `dtype`, rows ld* ELEMENTS apart (ld >= width: q / k / v may be column slices of one fused
+ * projection, out the second half of the [x | out] concatenation the reference returns).  Flash-style: the [L, L] score
+ * matrix is never materialised (the reference writes it: torch.bmm -> softmax -> torch.bmm); bf16: bf16 MFMA with fp32
+ * accumulation, probabilities rounded to bf16 for the second product; fp32: exact-fp32 MFMA throughout.
+ * Built for d_qk = 64, d_v = 256 (SelfAttention(256, downsample 4)); any L, any N <= 65535.
+ * ------------------------------------------------------------------------- */
+int mg_self_attention(const void* q, const void* k, const void* v, void* out, int32_t dtype, int32_t N, int32_t L,
+                      int32_t d_qk, int32_t d_v, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, void* stream);
 
 /* Fused Adam over one flat fp32 parameter buffer (torch.optim.Adam semantics,
  * pix2pix_model.py:137-145: eps 1e-8, no weight decay, bias correction).

@@ -15,7 +15,7 @@ MG_F32, MG_BF16 = 0, 1
 MG_ACT_NONE, MG_ACT_RELU, MG_ACT_LRELU, MG_ACT_TANH = 0, 1, 2, 3
 MG_EPI_PLAIN, MG_EPI_SPADE = 0, 1
 MG_MAX_TAPS = 64
-MG_ABI_VERSION = 4
+MG_ABI_VERSION = 5
 
 _i32, _f32, _vp, _i64 = ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
 
@@ -136,6 +136,7 @@ _PROTOS = {
     "mg_orient_loss_bwd": ([_vp, _vp, _vp, _i32, _i64, _vp, _i64, _vp, _vp, _vp, _i32, _i64, _vp, _vp], _i32),
     "mg_gabor_argmax_fwd": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
     "mg_gabor_argmax_bwd": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp], _i32),
+    "mg_self_attention": ([_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _vp], _i32),
     "mg_sn_normalize": ([_vp, _i32, _f32, _vp, _vp, _vp, _vp], _i32),
     "mg_sn_scale": ([_vp, _vp, _vp, _i64, _vp], _i32),
     "mg_sn_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp], _i32),

@@ -5,7 +5,8 @@ its caller models/pix2pix_model.py:407-429.  Parameters, buffers and nn.Sequenti
 `InpaintingModel_gen.pth` checkpoints load unchanged.  The network runs at 256x256 without gradients:
 7x7 / 4x4-stride-2 / dilated 3x3 / transposed 4x4 convolutions on the MFMA tap-list kernels (the transposed ones as
 per-parity-class gathers), InstanceNorm(+ReLU/LeakyReLU) on the fused norm kernels, reflection padding on the gather
-kernel; the 4096x4096 self-attention is two batched GEMMs + a softmax (rocBLAS through torch.bmm).
+kernel; the self-attention over the 4096 positions is one flash-style MFMA kernel (ops.self_attention, csrc/mg_attention.hip:
+QK^T -> online softmax -> PV per 128-query workgroup, the [4096, 4096] score matrix never exists).
 """
 from __future__ import annotations
 
@@ -70,12 +71,13 @@ class SelfAttention(nn.Module):
 
     def forward(self, x):                                   # NHWC
         n, h, w, c = x.shape
-        q = self.query_conv(x).reshape(n, h * w, -1).float()
-        k = self.key_conv(x).reshape(n, h * w, -1).float()
-        v = self.value_conv(x).reshape(n, h * w, c).float()
-        attn = torch.softmax(torch.bmm(q, k.transpose(1, 2)), dim=-1)       # [n, HW, HW]
-        out = torch.bmm(attn, v).reshape(n, h, w, c).to(x.dtype)
-        return torch.cat([x, out], dim=3)
+        q = self.query_conv(x).reshape(n, h * w, -1)
+        k = self.key_conv(x).reshape(n, h * w, -1)
+        v = self.value_conv(x).reshape(n, h * w, c)
+        y = torch.empty((n, h, w, 2 * c), dtype=x.dtype, device=x.device)     # [x | attention] (generator.py:485), written in place
+        y[..., :c] = x
+        ops.self_attention(q, k, v, out=y.reshape(n, h * w, 2 * c)[:, :, c:])
+        return y
 
 
 class InpaintGenerator(BaseNetwork):

@@ -1690,6 +1690,25 @@ def gabor_argmax(img_nhwc: torch.Tensor, bank: torch.Tensor):
     return _GaborMaxFn.apply(img_nhwc, bank)
 
 
+def self_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[n, i] = sum_j softmax_j(q[n, i] . k[n, j]) v[n, j] over the L positions of each sample (generator.py:467-485; no 1/sqrt(d)
+    scale), inference only.  q, k: [N, L, 64], v: [N, L, 256] in the compute dtype; each may be a column slice of a wider row-major
+    tensor (last-dim stride 1, uniform row pitch), and so may `out` ([N, L, 256], e.g. the second half of the [x | attention]
+    concatenation).  One flash-style launch: the [L, L] score matrix never exists (mg_attention.hip)."""
+    n, l, dqk = q.shape
+    dv = v.shape[2]
+    if out is None:
+        out = torch.empty((n, l, dv), dtype=v.dtype, device=v.device)
+
+    def pitch(t, width):
+        if t.shape != (n, l, width) or t.dtype != v.dtype or t.stride(2) != 1 or (n > 1 and t.stride(0) != l * t.stride(1)):
+            raise ValueError("self_attention: operands must be [N, L, width] with dense channels and a uniform row pitch, same dtype")
+        return t.stride(1)
+    C.backend().mg_self_attention(_p(q), _p(k), _p(v), _p(out), _dt(v), n, l, dqk, dv, pitch(q, dqk), pitch(k, dqk), pitch(v, dv), pitch(out, dv),
+                                  _stream(v))
+    return out
+
+
 class _SpectralScaleFn(torch.autograd.Function):
     """W_sn = W / sigma with sigma = u^T W v, u and v constants: dW = (g - (sum g * W_sn) u v^T) / sigma."""
 

@@ -82,7 +82,7 @@ class EmulatorBackend:
 
     # -- bookkeeping ---------------------------------------------------------
     def mg_abi_version(self):
-        return 4
+        return 5
 
     def mg_wgrad_det_workspace(self, d):
         return 16            # the emulator's weight gradient is a deterministic float64 sum: nothing to size
@@ -583,6 +583,19 @@ class EmulatorBackend:
         out.zero_()
         for c, wgt in enumerate((0.299, 0.587, 0.144)):
             out[..., c] = (dgray * wgt * 127.5).to(td)
+        return 0
+
+    def mg_self_attention(self, q, k, v, out, dtype, N, L, d_qk, d_v, ldq, ldk, ldv, ldo, stream=None):
+        """Contract of mg_self_attention (generator.py:467-485): float64 softmax(q k^T) v, one rounding to the storage dtype."""
+        td = _TD[dtype]
+        es = torch.empty((), dtype=td).element_size()
+
+        def rows(p, ld, width):            # [N, L, width] strided view of rows `ld` elements apart
+            flat = _view(p, ((N * L - 1) * ld + width,), td)
+            return flat.as_strided((N, L, width), (L * ld, ld, 1))
+        qv, kv, vv = rows(q, ldq, d_qk).double(), rows(k, ldk, d_qk).double(), rows(v, ldv, d_v).double()
+        res = torch.softmax(qv @ kv.transpose(1, 2), dim=-1) @ vv                          # [N, L, d_v]
+        rows(out, ldo, d_v)[:] = res.to(td)
         return 0
 
     def mg_sn_normalize(self, t, n, eps, dst, dst2, sigma, stream=None):

@@ -1193,3 +1193,31 @@ def test_wgrad_wide_channels_match_torch_gpu(shape):
     ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (cout, cin, 3, 3), dy.float().permute(0, 3, 1, 2), padding=1)
     _close("wgrad3x3 vs torch gpu", got, ref, 2e-3)
     _close("bias gradient", db[:cout], dy.float().sum((0, 1, 2)), 2e-3)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_self_attention_matches_contract(hip_backend, dt):
+    """mg_self_attention (flash-style QK^T -> online softmax -> PV, mg_attention.hip) vs the float64 contract softmax(q k^T) v of
+    generator.py:467-485 on identical operands: the in-painting net's real geometry (4096 positions), a one-tile problem, ragged
+    lengths (masked last key tile, partial query tile), peaky scores (|q . k| up to ~100: the running-max rescale fires late in the
+    key loop -- one key row is planted near the END that dominates one query), operands that are column slices of one fused
+    [q | k | v] projection, and the output written into the second half of a wider buffer."""
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(21)
+    tol = 2e-5 if dt == "f32" else 2.0 ** -7
+    for (n, L, scale, fused) in ((2, 4096, 0.35, False), (1, 256, 1.0, False), (3, 200, 0.5, True), (1, 333, 1.5, False), (2, 64, 0.2, True)):
+        q = (torch.randn(n, L, 64, generator=g) * scale).to(DT[dt])
+        k = (torch.randn(n, L, 64, generator=g) * scale).to(DT[dt])
+        v = torch.randn(n, L, 256, generator=g).to(DT[dt])
+        k[:, L - 5] = (4.0 * q[:, 7].float()).to(DT[dt])               # query 7's maximum arrives in the last key tile
+
+        def fn(q, k, v):
+            if fused:
+                qkv = torch.cat([q, k, v], dim=2).contiguous()
+                q, k, v = qkv[:, :, :64], qkv[:, :, 64:128], qkv[:, :, 128:]
+            buf = torch.zeros((q.shape[0], q.shape[1], 512), dtype=v.dtype, device=v.device)
+            ops.self_attention(q, k, v, out=buf[:, :, 256:])
+            return (buf,)
+        (hip, _), (ref, _) = _both(fn, (q, k, v))
+        assert torch.equal(hip[0][:, :, :256].cpu(), torch.zeros_like(ref[0][:, :, :256])), "wrote outside its half of the rows"
+        _close(f"self_attention {dt} n={n} L={L}", hip[0][:, :, 256:], ref[0][:, :, 256:], tol)

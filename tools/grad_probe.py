@@ -67,7 +67,8 @@ def oracle(dt):
         t.retain_grad()
     (out * gy.to(dt)).sum().backward()
     tg = {n: t.grad.double() for n, t in taps.items()}
-    return out.detach().double(), {k: v.grad.double() for k, v in osd.items() if v.requires_grad and v.grad is not None}, tg
+    tf = {n: t.detach().double() for n, t in taps.items()}
+    return out.detach().double(), {k: v.grad.double() for k, v in osd.items() if v.requires_grad and v.grad is not None}, tg, tf
 
 
 def hip():
@@ -92,19 +93,25 @@ def hip():
     for h in hooks:
         h.remove()
     tg = {n: t.grad.detach().float().cpu().permute(0, 3, 1, 2).double() for n, t in caught.items() if t.grad is not None}     # NHWC -> NCHW
-    return out.detach().double().cpu(), {n: p.grad.detach().double().cpu() for n, p in G.named_parameters() if p.grad is not None}, tg
+    tf = {n: t.detach().float().cpu().permute(0, 3, 1, 2).double() for n, t in caught.items()}
+    return out.detach().double().cpu(), {n: p.grad.detach().double().cpu() for n, p in G.named_parameters() if p.grad is not None}, tg, tf
 
 
 print("oracle fp64 ...", flush=True)
-o64, g64, t64 = oracle(torch.float64)
+o64, g64, t64, f64 = oracle(torch.float64)
 print("oracle fp32 ...", flush=True)
-o32, g32, t32 = oracle(torch.float32)
+o32, g32, t32, f32 = oracle(torch.float32)
 oracle_block = {n: ("%s_block" % n if n.startswith("up_") else n) for n in BLOCKS}
 
 
 def report(tag, full=True):
-    oh, gh, th = hip()
+    oh, gh, th, fh = hip()
     print("== %s: image L_inf vs fp64 %.2e (ATen32 %.2e)" % (tag, (oh - o64).abs().max().item(), (o32 - o64).abs().max().item()))
+    print("   FORWARD block outputs, HIP | ATen32: max-abs error / max-abs; relative L2")
+    for n in BLOCKS:
+        k = oracle_block[n]
+        if n in fh and k in f64:
+            print("     %-13s max %.1e | %.1e   L2 %.1e | %.1e   (max |value| %.1f)" % (n, rel(fh[n], f64[k]), rel(f32[k], f64[k]), rl2(fh[n], f64[k]), rl2(f32[k], f64[k]), f64[k].abs().max().item()))
     print("   gradient at block outputs, HIP | ATen32: max-abs error / max-abs of the fp64 gradient; relative L2; sign-flip-like elements:")
     for n in reversed(BLOCKS):
         k = oracle_block[n]
