@@ -45,6 +45,8 @@ def parse():
                     help="also run the frozen orientation in-painting net in both phases (BASELINE configs[4], --use_ig)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 --pmc passes behind roofline.traffic (two short child runs of this script)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the BASELINE configs[1] leg (generator forward, fp32, bs 4) reported under `extra`")
     return ap.parse_args()
 
 
@@ -102,6 +104,63 @@ class ConvMeter:
         return len(self.records), ms, fl, (len(dom), sum(r[0].elapsed_time(r[1]) for r in dom), sum(r[2] for r in dom), sum(r[5] for r in dom))
 
 
+DOMINANT = "conv3x3_halo_kernel<unsigned short, 1, 2, 4"          # the fused SPADE gamma|beta conv in rocprofv3's kernel names
+
+
+def measure_traffic_in_run(a, timeout_s: float = 240.0):
+    """roofline.traffic measured by THIS invocation: two child runs of this script (one warm-up + one timed step each) under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, --kernel-trace only: the TCC has 4 counter slots, FETCH_SIZE
+    takes 3, WRITE_SIZE 2), HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE (KiB units; gfx950 counts a 128-byte read request as 64 B:
+    MI355X_MICROARCH.md, HBM section).  Returns a dict or None (no rocprofv3 / a pass failed / timed out: the caller falls back to the
+    stamped profiles/ file and says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    tot, calls = {}, 0
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = ["rocprofv3", "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, c), "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-roofline", "--no-cpu-baseline",
+                   "--no-traffic", "--no-extra", "--batch-per-gpu", str(a.batch_per_gpu), "--size", str(a.size), "--dtype", a.dtype]
+            if a.inpaint_orient:
+                cmd.append("--inpaint-orient")
+            try:
+                res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            except (subprocess.TimeoutExpired, OSError):
+                return None
+            files = glob.glob(os.path.join(tmp, c, "**", "*counter_collection.csv"), recursive=True)
+            if res.returncode != 0 or not files:
+                return None
+            acc = {"conv": 0.0, "wgrad": 0.0, "all": 0.0, "dominant": 0.0}
+            n = 0
+            with open(files[0]) as fh:
+                for r in csv.DictReader(fh):
+                    if r["Counter_Name"] != c:
+                        continue
+                    v, k = float(r["Counter_Value"]), r["Kernel_Name"]
+                    acc["all"] += v
+                    if "conv_taps" in k or "conv3x3_halo" in k or "conv3x3_thin" in k or "conv_dot" in k or "conv_fewout" in k or "conv_thin" in k:
+                        acc["conv"] += v
+                    if "wgrad" in k:
+                        acc["wgrad"] += v
+                    if DOMINANT in k:
+                        acc["dominant"] += v
+                        n += 1
+            tot[c], calls = acc, n
+    steps = 2.0                                                      # warm-up step + timed step of the child
+    byts = lambda k: (2 * tot["FETCH_SIZE"][k] + tot["WRITE_SIZE"][k]) * 1024
+    out = {k + "_gb_per_step": round(byts(k) / steps / 1e9, 2) for k in ("conv", "wgrad", "all")}
+    if calls:
+        out["dominant_gb_per_launch"] = round(byts("dominant") / calls / 1e9, 3)
+        out["dominant_launches_seen"] = calls
+    return out
+
+
 def self_spawn(a) -> int:
     """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves, exactly as the
     driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` would, one
@@ -122,6 +181,39 @@ def self_spawn(a) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on these hosts (RCCL across processes)
     return subprocess.call(cmd, env=env)
+
+
+def gfwd_fp32_leg(a, local):
+    """BASELINE.json configs[1] beside the headline line: SPADEB generator forward only, bs 4, fp32 (exact-fp32 MFMA), no_grad, train-mode
+    batch norm -- the reference's own arithmetic.  Three warm-up + five timed forwards; conv launches of one more forward against the fp32
+    MFMA peak."""
+    import contextlib
+    from michigan_amd.model import Pix2PixTrainer, default_options
+    from michigan_amd.synth import synth_batch
+    torch.manual_seed(0)
+    opt = default_options(crop_size=a.size, gpu_ids=[local], compute_dtype="fp32")
+    with contextlib.redirect_stdout(sys.stderr):
+        tr = Pix2PixTrainer(opt)
+    data = {k: v.cuda() for k, v in synth_batch(4, a.size, seed=1234).items()}
+    fwd = lambda: tr.pix2pix_model(data, mode="inference")
+    for _ in range(3):
+        fwd()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        fwd()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    with ConvMeter() as m:
+        fwd()
+    n, ms, fl, _ = m.summary()
+    ach = fl / (ms * 1e-3) / 1e12
+    del tr, data
+    torch.cuda.empty_cache()
+    return {"value": round(4 / dt, 2), "unit": "images/s", "ms_per_forward": round(dt * 1e3, 2), "dtype": "f32", "batch": 4,
+            "workload": "SPADEB generator forward only (no_grad, train-mode BN), bs=4, %dx%d, BASELINE.json configs[1]" % (a.size, a.size),
+            "conv_launches": n, "conv_tflops": round(ach, 1), "conv_frac_of_f32_mfma_peak": round(ach / PEAK_F32_TFLOPS, 4),
+            "gflop_per_image": F_G}
 
 
 def main():
@@ -209,12 +301,21 @@ def main():
     if not a.no_roofline:
         # one extra, untimed step with HIP-event timing of every conv launch.  EVERY rank runs it (the step
         # contains collectives); only rank 0 reports.
-        from michigan_amd import parallel as _par
+        from michigan_amd import ops as _ops, parallel as _par
         _par.reset_collective_counts()
+        _ops.SYNC_BN_EVENTS = [] if (world > 1 or os.environ.get("MG_DP_FORCE") == "1") else None
         with ConvMeter() as m:
             step()
         n, ms, fl, (dn, dms, dfl, dbytes) = m.summary()
         collectives = dict(_par.COLLECTIVES)
+        syncbn_ms = None
+        if _ops.SYNC_BN_EVENTS is not None:
+            # what the sync-BN all-reduces of ONE step occupy on this rank's compute stream (HIP events around each: kernel time + the wait for
+            # the slowest rank); with MG_SYNCBN_ASYNC=1 they run on the process group's stream and the events bracket only the enqueue
+            ev, _ops.SYNC_BN_EVENTS = _ops.SYNC_BN_EVENTS, None
+            syncbn_ms = {k: round(sum(s_.elapsed_time(e_) for kk, s_, e_ in ev if kk == k), 3) for k in ("syncbn_fwd", "syncbn_bwd")}
+            syncbn_ms["count"] = len(ev)
+            syncbn_ms["form"] = "process group stream (MG_SYNCBN_ASYNC=1)" if _ops.SYNC_BN_ASYNC else "in-stream"
         if rank == 0:
             peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
             ach = fl / (ms * 1e-3) / 1e12
@@ -236,9 +337,21 @@ def main():
                         "unit": "TFLOP/s", "frac": all_conv["frac"], "traffic": None, "all_conv_launches": all_conv}
             # like-for-like across rounds: the aggregate over ALL conv launches next to the dominant kernel's figures, by name
             roof["dominant_kernel_frac"], roof["all_conv_frac"], roof["all_conv_achieved"] = roof["frac"], all_conv["frac"], all_conv["achieved"]
-            tfile = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r03_conv_traffic.json", "r02_conv_traffic.json")) if os.path.exists(f)), "")
-            # ^ tools/pmc_step.sh (rocprofv3 --pmc passes, separate runs)
-            if a.mode == "train" and a.dtype == "bf16" and a.batch_per_gpu == 8 and a.size == 512 and os.path.exists(tfile):
+            live = None
+            if a.mode == "train" and world == 1 and not a.no_traffic:
+                live = measure_traffic_in_run(a)
+            tfile = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json")) if os.path.exists(f)), "")
+            # ^ tools/pmc_step.sh (rocprofv3 --pmc passes, separate runs): the fallback when rocprofv3 is not available in this run
+            if live is not None:
+                roof["traffic"] = live.get("dominant_gb_per_launch") if dn else None
+                roof["traffic_unit"] = "GB of HBM per launch of the same kernel (2*FETCH_SIZE + WRITE_SIZE)"
+                all_conv["traffic_gb_per_step"] = live["conv_gb_per_step"]
+                roof["traffic_all_kernels_gb_per_step"] = live["all_gb_per_step"]
+                roof["traffic_wgrad_gb_per_step"] = live["wgrad_gb_per_step"]
+                roof["traffic_source"] = ("in-run: two child runs of this command (1 warm-up + 1 step) under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                                          "(separate passes, --kernel-trace only), on this box, these kernel sources")
+                roof["traffic_same_kernel_sources"] = True
+            elif a.mode == "train" and a.dtype == "bf16" and a.batch_per_gpu == 8 and a.size == 512 and os.path.exists(tfile):
                 with open(tfile) as fh:
                     tj = json.load(fh)
                 dk = tj.get("dominant")
@@ -246,8 +359,8 @@ def main():
                     roof["traffic"] = round(dk["hbm_bytes_per_launch"] / 1e9, 3)
                     roof["traffic_unit"] = "GB of HBM per launch of the same kernel (2*FETCH_SIZE + WRITE_SIZE)"
                 all_conv["traffic_gb_per_step"] = round(tj["conv"]["hbm_bytes_per_step"] / 1e9, 2)
-                roof["traffic_source"] = ("profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at commit %s"
-                                          % (os.path.basename(tfile), tj.get("commit")))
+                roof["traffic_source"] = ("stamped file (rocprofv3 not usable in this run): profiles/%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                          "passes at commit %s" % (os.path.basename(tfile), tj.get("commit")))
                 from michigan_amd.build import source_hash
                 # the PMC passes are separate runs: say whether they were taken on THESE kernel sources (hash of csrc/ + include/ + flags)
                 roof["traffic_same_kernel_sources"] = tj.get("kernel_sources") == source_hash()
@@ -281,13 +394,22 @@ def main():
             out["rank_spread_ms"] = round(max(per_rank_ms) - min(per_rank_ms), 3)
         if roof is not None and world > 1:
             out["collectives_per_step"] = collectives          # RCCL all-reduces one rank issues per G+D step, by kind
+        if roof is not None and syncbn_ms is not None:
+            out["syncbn_allreduce_ms_per_step"] = syncbn_ms    # rank 0's compute stream inside the sync-BN reductions of one step
         if roof is not None:
             out["roofline"] = roof
+        if world == 1 and a.mode == "train" and not a.no_extra and a.dtype == "bf16":
+            out["extra"] = {"configs1_generator_forward_fp32": gfwd_fp32_leg(a, local)}
         if world == 1 and not a.no_cpu_baseline and a.mode == "train":
-            from oracle.cpu_baseline import bounded_baseline
-            ips, threads, what = bounded_baseline(a.size)
-            out["cpu_baseline"] = {"value": round(ips, 4), "unit": "images/s", "cores": threads, "kind": "port",
-                                   "sample": "torch-CPU restatement of the reference (oracle/): " + what}
+            from oracle.cpu_baseline import bounded_baseline, reference_baseline
+            ref = reference_baseline(a.size)                   # the UNMODIFIED reference, where its checkout exists (never on the driver's GPU box)
+            if ref is not None:
+                ips, threads, what = ref
+                out["cpu_baseline"] = {"value": round(ips, 4), "unit": "images/s", "cores": threads, "kind": "reference", "sample": what}
+            else:
+                ips, threads, what = bounded_baseline(a.size)
+                out["cpu_baseline"] = {"value": round(ips, 4), "unit": "images/s", "cores": threads, "kind": "port",
+                                       "sample": "torch-CPU restatement of the reference (oracle/): " + what}
             rvp = os.path.join(ROOT, "profiles", "r03_cpu_reference_vs_port.json")
             if os.path.exists(rvp):                            # the real reference cannot travel to this box: how the port relates to it where both run
                 with open(rvp) as fh:

@@ -165,10 +165,11 @@ int mg_channel_stats_finalize(const void* x, int32_t dtype, int32_t G, int64_t P
 int mg_norm_finalize(const double* sums, int32_t G, int32_t C, double count, float eps, float momentum,
                      float* running_mean, float* running_var, float* mean, float* rstd, void* stream);
 
-/* y = act((x - mean[g][c]) * rstd[g][c])   (InstanceNorm2d + LeakyReLU,
- * discriminator.py:88-93, encoder.py:188-197) */
+/* y = act((x - mean[g][c]) * rstd[g][c]) [+ resid]   (InstanceNorm2d + LeakyReLU, discriminator.py:88-93, encoder.py:188-197;
+ * resid != NULL: the skip connection of the in-painting net's residual blocks, generator.py:463 `x + self.conv_block(x)`,
+ * same shape and dtype as y, added after the activation) */
 int mg_norm_act_fwd(const void* x, void* y, int32_t dtype, int32_t G, int64_t P, int32_t C,
-                    const float* mean, const float* rstd, int32_t act, float slope, void* stream);
+                    const float* mean, const float* rstd, int32_t act, float slope, const void* resid, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Backward of  h = act(xhat * g1 + beta),  xhat = (x - mean) * rstd

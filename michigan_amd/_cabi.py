@@ -95,7 +95,7 @@ _PROTOS = {
     "mg_channel_stats": ([_vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp], _i32),
     "mg_channel_stats_finalize": ([_vp, _i32, _i32, _i64, _i32, _f32, ctypes.c_double, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i32),
     "mg_norm_finalize": ([_vp, _i32, _i32, ctypes.c_double, _f32, _f32, _vp, _vp, _vp, _vp, _vp], _i32),
-    "mg_norm_act_fwd": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _f32, _vp], _i32),
+    "mg_norm_act_fwd": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _f32, _vp, _vp], _i32),
     "mg_norm_bwd_reduce": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp], _i32),
     "mg_norm_bwd_apply": ([_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _f32, _i32, _f32, _vp, _vp], _i32),
     "mg_norm_bwd_apply2": ([ctypes.POINTER(NormApply2Desc), _vp], _i32),

@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void reduce_stage2(const float* __restrict__ p
 
 template <typename T>
 __global__ void norm_act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t nquads, int64_t P, int C,
-                                    const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope)
+                                    const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope,
+                                    const T* __restrict__ resid)
 {
     const int c4 = C / 4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * blockDim.x) {
@@ -175,6 +176,11 @@ __global__ void norm_act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             o[j] = mg_act((xv[j] - mean[(size_t)g * C + c + j]) * rstd[(size_t)g * C + c + j], act, slope);
+        if (resid) {
+            const f32x4_t rv = ET<T>::load4(resid + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += rv[j];
+        }
         ET<T>::store4(y + i * 4, o);
     }
 }
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(NTHR) void norm_bwd_apply_vec(const T* __restrict__
 template <typename T, int PIX>
 __global__ __launch_bounds__(NTHR) void norm_act_fwd_vec(const T* __restrict__ x, T* __restrict__ y, int64_t P, int C,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                       float neg, bool relu)
+                                                       float neg, bool relu, const T* __restrict__ resid)
 {
     constexpr int VEC = VT<T>::VEC;
     const int cv = C / VEC, rows = NTHR / cv;
@@ -319,9 +325,12 @@ __global__ __launch_bounds__(NTHR) void norm_act_fwd_vec(const T* __restrict__ x
     const size_t base = (size_t)g * P * C + c;
     const int64_t step = (int64_t)gridDim.x * rows;
     for (int64_t p0 = (int64_t)blockIdx.x * rows + tr; p0 < P; p0 += step * PIX) {
-        float xv[PIX][VEC];
+        float xv[PIX][VEC], rv[PIX][VEC];
 #pragma unroll
-        for (int k = 0; k < PIX; ++k) { const int64_t p = p0 + k * step; if (p < P) VT<T>::load(x + base + (size_t)p * C, xv[k]); }
+        for (int k = 0; k < PIX; ++k) {
+            const int64_t p = p0 + k * step;
+            if (p < P) { VT<T>::load(x + base + (size_t)p * C, xv[k]); if (resid) VT<T>::load(resid + base + (size_t)p * C, rv[k]); }
+        }
 #pragma unroll
         for (int k = 0; k < PIX; ++k) {
             const int64_t p = p0 + k * step;
@@ -332,6 +341,7 @@ __global__ __launch_bounds__(NTHR) void norm_act_fwd_vec(const T* __restrict__ x
                     const float v = (xv[k][j] - m[j]) * r[j];
                     const float t = v > 0.f ? v : v * neg;
                     o4[j] = relu ? fmaxf(v, 0.f) : t;
+                    if (resid) o4[j] += rv[k][j];
                 }
                 VT<T>::store(y + base + (size_t)p * C, o4);
             }
@@ -726,7 +736,7 @@ extern "C" int mg_channel_stats_finalize(const void* x, int32_t dtype, int32_t G
 }
 
 extern "C" int mg_norm_act_fwd(const void* x, void* y, int32_t dtype, int32_t G, int64_t P, int32_t C,
-                               const float* mean, const float* rstd, int32_t act, float slope, void* stream)
+                               const float* mean, const float* rstd, int32_t act, float slope, const void* resid, void* stream)
 {
     MG_CHECK_NORM_GEOM("mg_norm_act_fwd");
     MG_CHECK_ARG(x && y && mean && rstd, "mg_norm_act_fwd: null pointer");
@@ -738,21 +748,21 @@ extern "C" int mg_norm_act_fwd(const void* x, void* y, int32_t dtype, int32_t G,
         if (dtype == MG_BF16) {
             const int rows = NTHR / (C / 8);
             hipLaunchKernelGGL((norm_act_fwd_vec<uint16_t, 4>), dim3(pix_grid(P, rows, 4, G), G), dim3(NTHR), 0, st,
-                               (const uint16_t*)x, (uint16_t*)y, P, C, mean, rstd, neg, relu);
+                               (const uint16_t*)x, (uint16_t*)y, P, C, mean, rstd, neg, relu, (const uint16_t*)resid);
         } else {
             const int rows = NTHR / (C / 4);
             hipLaunchKernelGGL((norm_act_fwd_vec<float, 4>), dim3(pix_grid(P, rows, 4, G), G), dim3(NTHR), 0, st,
-                               (const float*)x, (float*)y, P, C, mean, rstd, neg, relu);
+                               (const float*)x, (float*)y, P, C, mean, rstd, neg, relu, (const float*)resid);
         }
         MG_CHECK_LAUNCH("mg_norm_act_fwd");
         return MG_OK;
     }
     if (dtype == MG_BF16)
         hipLaunchKernelGGL(norm_act_fwd_kernel<uint16_t>, dim3(ew_grid(nq)), dim3(NTHR), 0, st,
-                           (const uint16_t*)x, (uint16_t*)y, nq, P, C, mean, rstd, act, slope);
+                           (const uint16_t*)x, (uint16_t*)y, nq, P, C, mean, rstd, act, slope, (const uint16_t*)resid);
     else
         hipLaunchKernelGGL(norm_act_fwd_kernel<float>, dim3(ew_grid(nq)), dim3(NTHR), 0, st,
-                           (const float*)x, (float*)y, nq, P, C, mean, rstd, act, slope);
+                           (const float*)x, (float*)y, nq, P, C, mean, rstd, act, slope, (const float*)resid);
     MG_CHECK_LAUNCH("mg_norm_act_fwd");
     return MG_OK;
 }

@@ -90,6 +90,85 @@ def init_distributed(backend: Optional[str] = None) -> bool:
     return True
 
 
+def _rank_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _save_network_rank0(net, label, epoch, opt):
+    """util.save_network (util/util.py:195-200) for a process-per-GPU job: the reference's version runs on EVERY rank -- `net.cpu()`,
+    then `torch.save` to the same `<epoch>_net_<label>.pth` concurrently -- which can leave a torn file.  Here rank 0 writes a CPU copy
+    of the state_dict to a temporary file and renames it into place (readers see the old or the new checkpoint, never a partial one),
+    the other ranks hold identical weights and only wait at the barrier; the network stays on its device."""
+    import torch.distributed as dist
+    rank, world = _rank_world()
+    path = os.path.join(opt.checkpoints_dir, opt.name, "%s_net_%s.pth" % (epoch, label))
+    if rank == 0:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        sd = {k: v.detach().to("cpu", copy=True) for k, v in net.state_dict().items()}
+        tmp = "%s.tmp.%d" % (path, os.getpid())
+        torch.save(sd, tmp)
+        os.replace(tmp, path)
+    if world > 1:
+        dist.barrier()
+
+
+class _EpochShardSampler(torch.utils.data.distributed.DistributedSampler):
+    """DistributedSampler that advances its epoch by itself: the reference's train.py iterates the loader once per epoch and never
+    calls set_epoch (train.py:75-96), which would replay one shuffle forever."""
+
+    def __iter__(self):
+        it = super().__iter__()
+        self.set_epoch(self.epoch + 1)
+        return it
+
+
+def _sharded_create_dataloader(orig_module):
+    """data.create_dataloader (data/__init__.py:41-58) for a process-per-GPU job.  The reference builds ONE loader of `opt.batchSize`
+    samples that nn.DataParallel scatters over `opt.gpu_ids`; under torchrun every rank would build that same loader and -- with
+    --serial_batches or equal seeds -- feed identical samples: data parallelism that only duplicates work.  Here rank r of w draws a
+    disjoint 1/w of every epoch (shuffled consistently across ranks unless --serial_batches) in batches of batchSize / w, so the global
+    batch per iteration stays `opt.batchSize` like the reference's."""
+    def create_dataloader(opt, step=1):
+        rank, world = _rank_world()
+        if world == 1:
+            return orig_module._mg_orig_create_dataloader(opt, step)
+        dataset = orig_module.find_dataset_using_name(opt.dataset_mode)
+        instance = dataset()
+        if "custom" in opt.dataset_mode:
+            instance.initialize(opt, step)
+        else:
+            instance.initialize(opt)
+        if opt.batchSize % world:
+            raise ValueError("michigan_amd.dropin: --batchSize %d is the GLOBAL batch and must be a multiple of the %d ranks" % (opt.batchSize, world))
+        print("dataset [%s] of size %d was created (rank %d of %d reads 1/%d of it, %d samples per batch)" %
+              (type(instance).__name__, len(instance), rank, world, world, opt.batchSize // world))
+        sampler = _EpochShardSampler(instance, num_replicas=world, rank=rank, shuffle=not opt.serial_batches, drop_last=bool(opt.isTrain))
+        return torch.utils.data.DataLoader(instance, batch_size=opt.batchSize // world, sampler=sampler, num_workers=int(opt.nThreads),
+                                           drop_last=bool(opt.isTrain))
+    return create_dataloader
+
+
+def _patch_job_side_effects():
+    """What every rank of a torchrun job would otherwise do identically and concurrently: checkpoint writes and data
+    loading.  Patched in the reference's own modules when they are importable; what stays the user's job is listed in INTEGRATION.md
+    (visualiser / loss-log output of `train.py` -- guard it with `if rank == 0` or accept one copy per rank)."""
+    try:
+        util = importlib.import_module("util.util")
+        _set("util.util", "save_network", _save_network_rank0)
+    except ImportError:                                   # pragma: no cover - the reference's util needs cv2 (may be absent)
+        pass
+    try:
+        data = importlib.import_module("data")
+        if not hasattr(data, "_mg_orig_create_dataloader"):
+            data._mg_orig_create_dataloader = data.create_dataloader
+        _set("data", "create_dataloader", _sharded_create_dataloader(data))
+    except ImportError:                                   # pragma: no cover - the reference's data package needs PIL / torchvision / cv2
+        pass
+
+
 def install(compute_dtype: Optional[str] = "fp32", losses: bool = True, data_parallel: bool = True,
             distributed: bool = True) -> Dict[str, type]:
     """Patch the HIP classes into the reference's `models.networks` package (which must be importable: the
@@ -97,7 +176,9 @@ def install(compute_dtype: Optional[str] = "fp32", losses: bool = True, data_par
     `losses=False` keeps the reference's loss classes (they then consume the HIP networks' NCHW outputs with ATen ops).
     `data_parallel=False` keeps the reference's nn.DataParallel wrapper.  `distributed`: join the torchrun job this process
     was started in, if any (`init_distributed`); the patched `DataParallelWithCallback` then makes the reference trainer data
-    parallel over the ranks.  Returns {name: patched class}.  Idempotent."""
+    parallel over the ranks, `util.save_network` writes on rank 0 only (temporary file + rename + barrier) and
+    `data.create_dataloader` hands every rank a disjoint 1 / world shard in batches of batchSize / world.
+    Returns {name: patched class}.  Idempotent."""
     global _INSTALLED
     if distributed and data_parallel:
         init_distributed()
@@ -150,6 +231,8 @@ def install(compute_dtype: Optional[str] = "fp32", losses: bool = True, data_par
             _set("models.networks.loss", name, cls)
             _set("models.networks", name, cls)
             patched[name] = cls
+    if data_parallel and distributed and _rank_world()[1] > 1:
+        _patch_job_side_effects()
     if data_parallel:
         _set("models.networks.sync_batchnorm", "DataParallelWithCallback", hip.DataParallelWithCallback)
         if "trainers.pix2pix_trainer" in sys.modules:                   # bound by `from ... import` at its import time

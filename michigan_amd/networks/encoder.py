@@ -144,7 +144,8 @@ class BackgroundEncode2(BaseNetwork):
                 return None
             th = int(mask_h * opt.random_expand_th)
             th = th if th % 2 == 1 else th + 1
-            return random.choice([max(th - 4, 1), max(th - 2, 1), th, th + 2, th + 4])
+            from .. import parallel                      # the draw must be the same on every rank of a data-parallel job
+            return parallel.shared_rng().choice([max(th - 4, 1), max(th - 2, 1), th, th + 2, th + 4])
         return opt.expand_th if opt.expand_mask_be else None
 
     def forward(self, image, mask, noise):              # all NCHW float (3 / 2 / 3 channels)

@@ -18,24 +18,60 @@ from .base_network import BaseNetwork
 from .layers import HipConv2d
 
 
+def _frozen_weight(m: nn.Module) -> torch.Tensor:
+    """The weight an eval-mode forward of `m` would use, computed ONCE per weight state.  torch's spectral_norm pre-hook recomputes
+    sigma = u . (W v) and W / sigma at every forward (eval mode: no power iteration, generator.py:452-461 via nn.utils.spectral_norm)
+    -- for the frozen in-painting net that was ~60 rocBLAS gemv + ~60 dot + ~80 weight re-packs per training step for values that
+    never change.  The result is a non-trainable Parameter, so ops.pack_weight's version-keyed cache keeps its GEMM image too."""
+    wo = getattr(m, "weight_orig", None)
+    if wo is None:
+        return m.weight
+    key = (wo.data_ptr(), wo._version, m.weight_u._version, m.weight_v._version, wo.device, wo.dtype)
+    hit = m.__dict__.get("_mg_frozen")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    w = None
+    for hook in m._forward_pre_hooks.values():
+        if hasattr(hook, "compute_weight"):                       # torch.nn.utils.spectral_norm.SpectralNorm
+            with torch.no_grad():
+                w = hook.compute_weight(m, do_power_iteration=False)
+    if w is None:
+        raise RuntimeError("spectral-normed module without its spectral_norm hook")
+    w = nn.Parameter(w.detach().clone(), requires_grad=False)
+    m.__dict__["_mg_frozen"] = (key, w)
+    return w
+
+
 class InferConv2d(nn.Conv2d):
     """nn.Conv2d parameters, inference-only forward (any dilation) on NHWC."""
 
-    def forward(self, x, act=ops.ACT_NONE, slope=0.2):
+    def forward(self, x, act=ops.ACT_NONE, slope=0.2, weight=None):
         if self.padding_mode != "zeros" or self.groups != 1 or self.kernel_size[0] != self.kernel_size[1]:
             raise NotImplementedError("InferConv2d: zero padding, groups 1, square kernels only")
-        return ops.conv2d_infer(x, self.weight, self.bias, stride=self.stride[0], padding=self.padding[0],
+        return ops.conv2d_infer(x, self.weight if weight is None else weight, self.bias, stride=self.stride[0], padding=self.padding[0],
                                 dilation=self.dilation[0], act=act, slope=slope)
+
+    def infer(self, x, act=ops.ACT_NONE, slope=0.2):
+        """forward() of the frozen net: in eval mode the (spectral-normed) weight comes from _frozen_weight and the module's pre-hooks
+        are not run; in training mode this is an ordinary call."""
+        if self.training:
+            return self(x, act=act, slope=slope)
+        return InferConv2d.forward(self, x, act=act, slope=slope, weight=_frozen_weight(self))
 
 
 class InferConvTranspose2d(nn.ConvTranspose2d):
     """nn.ConvTranspose2d parameters ([Cin, Cout, k, k]; spectral_norm picks dim=1 for this class, as in the
     reference), inference-only forward on NHWC."""
 
-    def forward(self, x):
+    def forward(self, x, weight=None):
         if self.output_padding != (0, 0) or self.groups != 1 or self.dilation != (1, 1):
             raise NotImplementedError("InferConvTranspose2d: no output padding / groups / dilation")
-        return ops.conv_transpose2d_infer(x, self.weight, self.bias, stride=self.stride[0], padding=self.padding[0])
+        return ops.conv_transpose2d_infer(x, self.weight if weight is None else weight, self.bias, stride=self.stride[0], padding=self.padding[0])
+
+    def infer(self, x):
+        if self.training:
+            return self(x)
+        return InferConvTranspose2d.forward(self, x, weight=_frozen_weight(self))
 
 
 def _sn(m):
@@ -53,10 +89,10 @@ class ResnetBlock(nn.Module):
 
     def forward(self, x):                                   # NHWC
         cb = self.conv_block
-        y = cb[1](ops.reflect_pad(x, 2))
-        y = ops.instance_norm_act(y, act=ops.ACT_RELU)
-        y = cb[5](ops.reflect_pad(y, 1))
-        return x + ops.instance_norm_act(y, act=ops.ACT_NONE)
+        y = cb[1].infer(ops.reflect_pad(x, 2))
+        y = ops.instance_norm_act_infer(y, act=ops.ACT_RELU)
+        y = cb[5].infer(ops.reflect_pad(y, 1))
+        return ops.instance_norm_act_infer(y, act=ops.ACT_NONE, resid=x)          # x + IN(...): the skip rides in the apply launch
 
 
 class SelfAttention(nn.Module):
@@ -71,9 +107,9 @@ class SelfAttention(nn.Module):
 
     def forward(self, x):                                   # NHWC
         n, h, w, c = x.shape
-        q = self.query_conv(x).reshape(n, h * w, -1)
-        k = self.key_conv(x).reshape(n, h * w, -1)
-        v = self.value_conv(x).reshape(n, h * w, c)
+        q = self.query_conv.infer(x).reshape(n, h * w, -1)
+        k = self.key_conv.infer(x).reshape(n, h * w, -1)
+        v = self.value_conv.infer(x).reshape(n, h * w, c)
         y = torch.empty((n, h, w, 2 * c), dtype=x.dtype, device=x.device)     # [x | attention] (generator.py:485), written in place
         y[..., :c] = x
         ops.self_attention(q, k, v, out=y.reshape(n, h * w, 2 * c)[:, :, c:])
@@ -100,11 +136,11 @@ class InpaintGenerator(BaseNetwork):
     def forward(self, x):                                   # NCHW [N, 4, H, W] -> NCHW [N, 3, H, W] in [0, 1]
         e, d = self.encoder, self.decoder
         y = ops.pad_channels(ops.to_nhwc(x, self.compute_dtype), 8)
-        y = ops.instance_norm_act(e[1](ops.reflect_pad(y, 3)), act=ops.ACT_LRELU, slope=0.2)
-        y = ops.instance_norm_act(e[4](y), act=ops.ACT_LRELU, slope=0.2)
-        y = ops.instance_norm_act(e[7](y), act=ops.ACT_LRELU, slope=0.2)
+        y = ops.instance_norm_act(e[1].infer(ops.reflect_pad(y, 3)), act=ops.ACT_LRELU, slope=0.2)
+        y = ops.instance_norm_act(e[4].infer(y), act=ops.ACT_LRELU, slope=0.2)
+        y = ops.instance_norm_act(e[7].infer(y), act=ops.ACT_LRELU, slope=0.2)
         y = self.middle(y)
-        y = ops.instance_norm_act(d[0](y), act=ops.ACT_RELU)
-        y = ops.instance_norm_act(d[3](y), act=ops.ACT_RELU)
-        y = d[7](ops.reflect_pad(y, 3), act=ops.ACT_TANH)
+        y = ops.instance_norm_act(d[0].infer(y), act=ops.ACT_RELU)
+        y = ops.instance_norm_act(d[3].infer(y), act=ops.ACT_RELU)
+        y = d[7].infer(ops.reflect_pad(y, 3), act=ops.ACT_TANH)
         return (ops.to_nchw(y).float()[:, :3] + 1) / 2

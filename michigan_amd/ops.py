@@ -55,6 +55,27 @@ def set_deterministic(flag: bool = True) -> bool:
     return prev
 
 
+# bench.py --gpus N: a list here makes every sync-BN all-reduce record a pair of HIP events on the compute stream around itself
+# ((kind, start, end) tuples), so that the first run on a real node shows what the ~42 latency-bound reductions of a step cost in-stream
+# (vs MG_SYNCBN_ASYNC=1) without a profiler.  None = no events.
+SYNC_BN_EVENTS = None
+
+
+def _sync_bn_all_reduce(t: torch.Tensor, kind: str):
+    import torch.distributed as dist
+    ev = SYNC_BN_EVENTS if t.is_cuda else None
+    if ev is not None:
+        s = torch.cuda.Event(enable_timing=True)
+        s.record()
+    work = dist.all_reduce(t, group=SYNC_BN_GROUP, async_op=SYNC_BN_ASYNC)
+    if ev is not None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        ev.append((kind, s, e))
+    _count_collective(kind)
+    return work
+
+
 STATS_FROM_UPSAMPLE_SOURCE = True     # batch statistics of a 2x-upsampled tensor from its quarter-size source (A/B: tools/ab_pyflag.py)
 
 
@@ -305,7 +326,10 @@ def unpack_wgrad(dw: torch.Tensor, shape, two: bool = False):
 
 FUSE_RELU_MASK = True   # fold a consumed ReLU's backward mask into the data-gradient epilogue (A/B switch)
 FUSE_LRELU_MASK = os.environ.get("MG_FUSE_LRELU_MASK", "1") != "0"    # ... and a single-consumer LeakyReLU's (SPADE outputs inside a residual block)
-MASK_PROTOCOL_CHECK = os.environ.get("MG_MASK_PROTOCOL_CHECK", "0") == "1"
+# The LeakyReLU mask is not idempotent, so its hand-off is checked on the host by default (one set lookup per SPADE backward): a producer
+# whose consumer committed to the fold at forward time raises if the gradient it receives is not the very buffer that consumer masked
+# (a hook cloned it, autograd summed it with another gradient, ...), instead of masking twice in silence.  ADVICE r3.
+MASK_PROTOCOL_CHECK = os.environ.get("MG_MASK_PROTOCOL_CHECK", "1") != "0"
 
 
 def mark_single_consumer_lrelu(t: torch.Tensor, slope: float = 0.2) -> torch.Tensor:
@@ -318,14 +342,35 @@ def mark_single_consumer_lrelu(t: torch.Tensor, slope: float = 0.2) -> torch.Ten
 
 def _grad_premasked(dh: torch.Tensor, h: torch.Tensor, act: int) -> bool:
     """True when `dh` (the gradient of the activation output `h`) was already multiplied by the activation's derivative by the
-    consumer's data-gradient epilogue (the record conv_dgrad left for exactly this buffer)."""
+    consumer's data-gradient epilogue (the record conv_dgrad left for exactly this buffer).
+
+    Two records, both keyed by addresses of buffers that are ALIVE between the two events they connect:
+      _FOLD_EXPECTED  address of h, added by the consuming conv2d at FORWARD time when it commits to folding h's LeakyReLU mask (h is saved by
+                      its producer until the producer's backward): tells the producer that an un-masked gradient would be an error;
+      _RELU_MASKED    address of the masked gradient -> (address of h, the gradient's version), left by conv_dgrad and popped here within
+                      the same backward pass (the gradient is referenced by the autograd engine in between).
+    reset_mask_protocol() (every optimiser zero_grad / trainer step) drops whatever an interrupted backward left behind."""
     if act not in (ACT_RELU, ACT_LRELU):
         return False
     hit = _RELU_MASKED.pop(dh.data_ptr(), None) == (h.data_ptr(), dh._version)
-    if MASK_PROTOCOL_CHECK and not hit and getattr(h, "_mg_lrelu_out", None) is not None and FUSE_LRELU_MASK:
-        raise RuntimeError("mask protocol: a single-consumer LeakyReLU output received a gradient its consumer did not pre-mask")
+    if act == ACT_LRELU and h.data_ptr() in _FOLD_EXPECTED:
+        _FOLD_EXPECTED.discard(h.data_ptr())
+        if MASK_PROTOCOL_CHECK and not hit and FUSE_LRELU_MASK and FUSE_RELU_MASK:
+            raise RuntimeError("mask protocol: the consumer of a single-consumer LeakyReLU output folded the activation's backward mask into its "
+                               "data gradient, but the gradient that reached the producer is not that buffer (cloned by a hook, accumulated with "
+                               "another gradient, made contiguous by a copy): masking again would scale negative-side gradients by slope^2.  "
+                               "Set MG_FUSE_LRELU_MASK=0 when gradients of SPADE outputs are intercepted.")
     return hit
+
+
+def reset_mask_protocol():
+    """Forget every pending mask hand-off (records of a backward pass that was interrupted, forward passes that never got a backward)."""
+    _RELU_MASKED.clear()
+    _FOLD_EXPECTED.clear()
+
+
 _RELU_MASKED = {}       # address of a ReLU-masked data gradient -> (address of the ReLU output it was masked with, version)
+_FOLD_EXPECTED = set()  # addresses of LeakyReLU outputs whose (single) consumer committed to the mask fold at forward time
 _DGRAD_CLASSES = {}     # (kh, kw, stride, pad) -> [(py, px, taps, (lo, hi))], tap order of the class-sorted weight image
 _DGRAD_PERM = {}        # (kh, kw, stride, pad, device) -> index tensor that sorts the packed taps by parity class
 
@@ -550,6 +595,8 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     fold, mslope = xp is x and getattr(x, "_mg_relu_out", False), 0.0
     if xp is x and not fold and FUSE_LRELU_MASK and getattr(x, "_mg_lrelu_out", None) is not None:
         fold, mslope = True, float(x._mg_lrelu_out)             # a LeakyReLU output whose producer named this conv its only consumer
+        if torch.is_grad_enabled() and x.requires_grad and FUSE_RELU_MASK:
+            _FOLD_EXPECTED.add(x.data_ptr())                    # this conv's data gradient WILL carry x's mask: its producer must find it so
     y = _Conv2dFn.apply(xp, weight, bias, resid, stride, padding, act, slope, fold, _sink_for(weight, bias), mslope)
     if act == ACT_RELU:
         y._mg_relu_out = True        # consumers may fold this ReLU's backward mask into their data-gradient epilogue
@@ -639,8 +686,7 @@ def batch_stats_begin(x: torch.Tensor, up: bool = False):
         work = None
         if SYNC_BN_GROUP is not None:
             import torch.distributed as dist
-            work = dist.all_reduce(sums, group=SYNC_BN_GROUP, async_op=SYNC_BN_ASYNC)
-            _count_collective("syncbn_fwd")
+            work = _sync_bn_all_reduce(sums, "syncbn_fwd")
             count *= dist.get_world_size(SYNC_BN_GROUP)
         return sums, work, count, c
 
@@ -852,9 +898,7 @@ class _SpadeFn(torch.autograd.Function):
         dx = dactv = dwg = dwb = dbg = dbb = None
         work = None
         if ctx.needs_input_grad[0] and SYNC_BN_GROUP is not None:
-            import torch.distributed as dist
-            work = dist.all_reduce(sums, group=SYNC_BN_GROUP, async_op=SYNC_BN_ASYNC)    # overlaps with the gamma/beta conv's backward below
-            _count_collective("syncbn_bwd")
+            work = _sync_bn_all_reduce(sums, "syncbn_bwd")    # overlaps with the gamma/beta conv's backward below
         if ctx.needs_input_grad[1]:
             wt = pack_weight(w_gamma, w_beta, x.dtype, _roundup(actv.shape[3], 128), rows, 1)
             dactv = conv_dgrad(dgb, wt, kh, kh, 1, pad, (hh, ww), actv.shape[3],
@@ -949,9 +993,7 @@ class _SpadePairFn(torch.autograd.Function):
             dgbs.append(dgb)
         work = None
         if need_x and SYNC_BN_GROUP is not None:
-            import torch.distributed as dist
-            work = dist.all_reduce(sums, group=SYNC_BN_GROUP, async_op=SYNC_BN_ASYNC)         # both branches in ONE collective; overlaps with the convs below
-            _count_collective("syncbn_bwd")
+            work = _sync_bn_all_reduce(sums, "syncbn_bwd")         # both branches in ONE collective; overlaps with the convs below
         grads = [None] * 11
         for b, (dh, h, g1, actv, wg, wb, base) in enumerate(branches):
             kh = wg.shape[2]
@@ -1037,7 +1079,7 @@ class _InstanceNormActFn(torch.autograd.Function):
             rstd = torch.empty((n, c), dtype=torch.float32, device=x.device)
             C.backend().mg_norm_finalize(_p(sums), n, c, float(p), eps, 0.0, None, None, _p(mean), _p(rstd), _stream(x))
         y = torch.empty_like(x)
-        C.backend().mg_norm_act_fwd(_p(x), _p(y), _dt(x), n, p, c, _p(mean), _p(rstd), act, slope, _stream(x))
+        C.backend().mg_norm_act_fwd(_p(x), _p(y), _dt(x), n, p, c, _p(mean), _p(rstd), act, slope, None, _stream(x))
         ctx.save_for_backward(x, y, mean, rstd)
         ctx.cfg = (act, slope)
         return y
@@ -1063,6 +1105,21 @@ class _InstanceNormActFn(torch.autograd.Function):
 def instance_norm_act(x, *, eps: float = 1e-5, act: int = ACT_NONE, slope: float = 0.2):
     """nn.InstanceNorm2d(affine=False) followed by an optional fused activation (NHWC)."""
     return _InstanceNormActFn.apply(x, eps, act, slope)
+
+
+def instance_norm_act_infer(x, *, eps: float = 1e-5, act: int = ACT_NONE, slope: float = 0.2, resid: Optional[torch.Tensor] = None):
+    """Inference-only instance norm + activation [+ resid] (the frozen in-painting net: `x + IN(conv(...))`, generator.py:463):
+    statistics (2 launches) and ONE apply launch that also adds the skip connection (was an extra element-wise launch per block)."""
+    x = _nhwc(x.detach())
+    n, h, w, c = x.shape
+    mean, rstd, _ = stats_finalize(x, n, float(h * w), eps)
+    if resid is not None:
+        resid = _nhwc(resid.detach())
+        if resid.shape != x.shape or resid.dtype != x.dtype:
+            raise ValueError("instance_norm_act_infer: the residual must match x")
+    y = torch.empty_like(x)
+    C.backend().mg_norm_act_fwd(_p(x), _p(y), _dt(x), n, h * w, c, _p(mean), _p(rstd), act, slope, _p(resid), _stream(x))
+    return y
 
 
 # ----------------------------------------------------------------------------

@@ -62,6 +62,7 @@ class FlatAdam:
         self.overlap = os.environ.get("MG_DP_OVERLAP", "1") != "0"
         self._launched_any = False       # a bucket of this step is (or was) in flight
         self._synced = False             # sync_grads() already summed this step's gradients over the ranks
+        self._consumed = False           # step() has applied them: gradients that arrive before the next zero_grad() are discardable
         self._drained_local = False      # rank-local gradients were drained into flat_grad before any reduction (overlap off)
         # ---- autograd-path buckets (all parameters when the sink is off; unused otherwise) ---------------------
         # bucket = contiguous [lo, hi) slice of the arena; params were laid out in REVERSE registration
@@ -129,6 +130,7 @@ class FlatAdam:
         self._table_host = self._table_dev = self._block_slot_dev = None
 
     def zero_grad(self, set_to_none: bool = False):
+        ops.reset_mask_protocol()                    # no backward pass is in flight here: drop hand-off records an interrupted one left
         self._wait_collectives()                     # of a backward whose gradients are being discarded
         self.flat_grad.zero_()
         if self.gemm is not None and any(s.written for s in self._slot_list):      # a backward without a step(): discard it
@@ -139,7 +141,7 @@ class FlatAdam:
                 p.grad = self.flat_grad[a:b].view(p.shape)
         self._pending = [b[2] for b in self.buckets]
         self._leftover = []
-        self._launched_any = self._drained_local = self._synced = False
+        self._launched_any = self._drained_local = self._synced = self._consumed = False
 
     # ---- gradient sink: GEMM-order arena ------------------------------------------------------------
     def owns(self, p) -> bool:
@@ -150,6 +152,11 @@ class FlatAdam:
         or None when this convolution has to stay on the autograd path.  `w1` / `b1`: the beta tensors of a fused SPADE
         gamma|beta pair.  `sn` = (W_sn, u, v, sigma) of the forward pass this gradient belongs to (spectral norm)."""
         if not self.sink or taps > 49 or not self.owns(w0) or (w1 is not None and not self.owns(w1)):
+            return None
+        if self._consumed:
+            # a backward pass between step() and the next zero_grad() -- the reference's loop back-propagates the generator loss into D
+            # after D.step() (pix2pix_trainer.py:64) and only D's next zero_grad() discards that: let autograd accumulate it into .grad,
+            # keep it out of the arena / the collectives (ADVICE r3)
             return None
         if any(b is not None and not self.owns(b) for b in (b0, b1)):
             return None
@@ -296,6 +303,8 @@ class FlatAdam:
                       "(sync_grads / finalize_grads / step); call zero_grad() first")
 
     def _on_grad(self, p):
+        if self._consumed:
+            return                                      # discardable gradient behind step(): no collective, no error (see grad_slot)
         if self._synced:
             raise RuntimeError(self._LATE_BACKWARD)
         if self.sink:
@@ -453,9 +462,15 @@ class FlatAdam:
             return                                   # buckets in flight: sync_grads raises / handles it
         for p in self._order:
             g = p.grad
-            if g is None:
-                continue
             a, b = self._span_of[id(p)]
+            if g is None:
+                # `module.zero_grad(set_to_none=True)` and no gradient since: this step's gradient is zero, but the slice may still hold an
+                # earlier step's (only optimizer.zero_grad() clears the arena) and the arena-wide kernel would apply it again.
+                # (torch.optim.Adam would SKIP such a parameter; the flat kernel updates it with g = 0 -- its moments decay.)
+                view = self.flat_grad[a:b].view(p.shape)
+                view.zero_()
+                p.grad = view
+                continue
             if g.data_ptr() != self.flat_grad.data_ptr() + 4 * a or g.dtype != torch.float32:
                 if self.dp and not self.sink and self.overlap:
                     raise RuntimeError("FlatAdam (data parallel): a parameter's .grad was detached from the gradient arena (zero_grad(set_to_none) on the "
@@ -475,3 +490,4 @@ class FlatAdam:
         ops.adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, lr=lr, beta1=self.betas[0],
                       beta2=self.betas[1], eps=self.eps, step=self.step_count, grad_scale=1.0 / self.world)
         self.weight_epoch += 1           # the kernel wrote the arena through raw pointers: cached packed weights (ops.pack_weight) are stale
+        self._consumed = True

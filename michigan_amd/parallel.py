@@ -14,11 +14,14 @@ The ~42 small sync-BN reductions of a step go on the compute stream instead: on 
 stream each costs two cross-stream dependencies (3.2 ms per step with one rank), about the latency it
 could hide (MG_SYNCBN_ASYNC=1 / MG_DP_GRAD_SIDE=0|1 select the other forms).
 
-Two traffic classes, two communicators: one RCCL communicator serialises its collectives, so an 8 KB
-statistics all-reduce issued behind an in-flight 64 MiB gradient bucket would wait for that bucket's
-ring time (42 times per step).  `init()` therefore creates a SECOND process group over the same ranks
-for the sync-BN reductions (`ops.SYNC_BN_GROUP`); gradient buckets keep the first (`grad_group()`).
-MG_DP_ONE_GROUP=1 puts both on one communicator again (A/B on a real node).
+Two traffic classes, ONE communicator by default.  One RCCL communicator serialises its collectives, so an 8 KB
+statistics all-reduce issued behind an in-flight 64 MiB gradient bucket waits for that bucket's ring time (up to
+42 times per step).  A second communicator over the same ranks for the sync-BN reductions avoids that wait, but
+concurrent collectives on two communicators of one process are the pattern the NCCL / RCCL documentation warns
+about (the kernels of the two communicators can be scheduled in different orders on different ranks and wait for
+each other's resources), and this code has never run on two physical GPUs -- so the split is OPT-IN:
+MG_DP_TWO_GROUPS=1 makes `init()` create the second process group (`ops.SYNC_BN_GROUP = bn_group()`), for the A/B
+on a real node; without it `bn_group() is grad_group()`.
 
 Two consumers:
   * this repo's trainer (`model.Pix2PixTrainer`): `optim.FlatAdam(group=grad_group())` reduces its GEMM-order
@@ -30,6 +33,7 @@ Two consumers:
 from __future__ import annotations
 
 import os
+import random
 from typing import List, Optional
 
 import torch
@@ -40,6 +44,7 @@ from . import ops
 _GROUP = None            # gradient buckets
 _BN_GROUP = None         # sync-BN statistics (a second communicator over the same ranks)
 _OWNED = []              # groups init() created (destroyed by shutdown())
+_SHARED_RNG: Optional[random.Random] = None       # host-side draws every rank must make identically (see shared_rng)
 
 
 def _forced() -> bool:
@@ -54,8 +59,9 @@ def init(group=None):
     Collective over those ranks (it creates process groups).  Returns the gradient group, or None when there is
     nothing to reduce (no process group / one rank).  Idempotent for the same `group`."""
     global _GROUP, _BN_GROUP
+    global _SHARED_RNG
     if not _forced() and (not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1):
-        _GROUP = _BN_GROUP = None
+        _GROUP = _BN_GROUP = _SHARED_RNG = None
         ops.SYNC_BN_GROUP = None
         return None
     base = group if group is not None else dist.group.WORLD
@@ -63,8 +69,8 @@ def init(group=None):
         return _GROUP
     init._base = base
     _GROUP = base
-    if os.environ.get("MG_DP_ONE_GROUP") == "1":
-        _BN_GROUP = base
+    if os.environ.get("MG_DP_TWO_GROUPS") != "1" or os.environ.get("MG_DP_ONE_GROUP") == "1":
+        _BN_GROUP = base                                  # default: both traffic classes on one communicator (see the module docstring)
     else:
         if base is dist.group.WORLD:
             _BN_GROUP = dist.new_group()
@@ -72,7 +78,35 @@ def init(group=None):
             _BN_GROUP = dist.new_group(ranks=dist.get_process_group_ranks(base), use_local_synchronization=True)
         _OWNED.append(_BN_GROUP)
     ops.SYNC_BN_GROUP = None if os.environ.get("MG_DP_NO_SYNCBN") == "1" else _BN_GROUP      # measurement switch
+    _init_shared_rng(base)
     return _GROUP
+
+
+def _init_shared_rng(group):
+    """One-time (collective) agreement on the seed of the shared host RNG: rank 0 draws it from ITS `random` module."""
+    global _SHARED_RNG
+    box = [random.getrandbits(62)]
+    src = dist.get_global_rank(group, 0) if group is not dist.group.WORLD else 0
+    dist.broadcast_object_list(box, src=src, group=group)
+    _SHARED_RNG = random.Random(box[0])
+
+
+def shared_rng():
+    """Where host-side random draws that shape the computation come from -- the background encoder's mask-growth kernel size
+    (encoder.py:288-297: `random.choice` per forward).  The reference's DataParallel replicas are threads of one process and share
+    the global `random`; ranks of a process-per-GPU job do not, and with per-rank draws an N-rank run differs from the 1-rank run on
+    the concatenated batch (allowed by SURVEY section 8e, but it makes N-vs-1 comparisons non-bitwise).  Data parallel: a dedicated
+    `random.Random` whose seed rank 0 broadcast ONCE at init() -- every rank makes the same draws with no per-step communication (the
+    draw is needed on the host, a per-step broadcast would be a device round trip).  Single process: the `random` module itself."""
+    return _SHARED_RNG if _SHARED_RNG is not None else random
+
+
+def seed_shared_rng(seed) -> None:
+    """`random.seed(seed)` plus the same seed for the shared RNG (call with the SAME value on every rank): after it a data-parallel
+    run draws exactly what a single process that called `random.seed(seed)` draws (tests / reproducible runs)."""
+    random.seed(seed)
+    if _SHARED_RNG is not None:
+        _SHARED_RNG.seed(seed)
 
 
 def shutdown():
@@ -84,6 +118,8 @@ def shutdown():
         except Exception:                                  # the default group went first: nothing left to destroy
             pass
     del _OWNED[:]
+    global _SHARED_RNG
+    _SHARED_RNG = None
     _GROUP = _BN_GROUP = None
     init._base = None
     ops.SYNC_BN_GROUP = None

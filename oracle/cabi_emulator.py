@@ -177,12 +177,15 @@ class EmulatorBackend:
             rv.mul_(1 - momentum).add_((var[0] * (count / max(count - 1, 1))).float(), alpha=momentum)
         return 0
 
-    def mg_norm_act_fwd(self, x, y, dtype, G, P, C, mean, rstd, act, slope, stream=None):
+    def mg_norm_act_fwd(self, x, y, dtype, G, P, C, mean, rstd, act, slope, resid=None, stream=None):
         td = _TD[dtype]
         xv = _view(x, (G, P, C), td).double()
         mu = _view(mean, (G, 1, C), torch.float32).double()
         rs = _view(rstd, (G, 1, C), torch.float32).double()
-        _view(y, (G, P, C), td)[:] = _act((xv - mu) * rs, act, slope).to(td)
+        out = _act((xv - mu) * rs, act, slope)
+        if _addr(resid):
+            out = out + _view(resid, (G, P, C), td).double()
+        _view(y, (G, P, C), td)[:] = out.to(td)
         return 0
 
     def _bwd_common(self, dh, h, x, g1, dtype, G, P, C, mean, rstd, act, slope):

@@ -90,3 +90,70 @@ def bounded_baseline(full_size: int = 512, budget_s: float = 40.0):
                                              f"scaled x{ratio:.0f} pixels to {full_size}x{full_size}")
     secs, n, threads = time_train_step(size=full_size, n=1, iters=1, warmup=1)
     return n / secs, threads, f"{what} at {full_size}x{full_size}, 1 timed iteration after 1 warm-up: {secs:.1f} s"
+
+
+def reference_baseline(full_size: int = 512, budget_s: float = 60.0):
+    """cpu_baseline kind "reference": the UNMODIFIED reference trainer (trainers/pix2pix_trainer.py run_generator_one_step +
+    run_discriminator_one_step, README training flags + --no_lab_loss, fp32) timed on the host cores through oracle/ref_harness.py --
+    only where its checkout exists (ref_harness.reference_available(): the builder container; never the driver's GPU box, which then
+    reports the port).  Runs in a CHILD interpreter: the harness makes `.cuda()` a no-op for the reference's hard-coded calls, which must
+    not leak into a process that drives a GPU.  Same bounded protocol as bounded_baseline: 256x256 first, the full size only if it fits
+    the budget.  Returns (images_per_second_at_full_size, threads, description) or None."""
+    import json
+    import subprocess
+    import sys
+    from oracle import ref_harness as R
+    if not R.reference_available():
+        return None
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        res = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from oracle import cpu_baseline as B; B._reference_child(%d, %r)"
+                              % (root, full_size, budget_s)], capture_output=True, text=True, timeout=20 * budget_s, env=env)
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+        j = json.loads(line)
+        return j["ips"], j["threads"], j["what"]
+    except Exception:                                                         # the reference leg is optional: the port is reported instead
+        return None
+
+
+def _reference_child(full_size: int, budget_s: float):
+    import contextlib
+    import json
+    import sys
+    import tempfile
+    from oracle import ref_harness as R
+    from michigan_amd.synth import synth_loader_batch
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    R.setup()
+    from trainers.pix2pix_trainer import Pix2PixTrainer                     # the reference's own
+
+    def run(size):
+        with tempfile.TemporaryDirectory() as ck:
+            argv = ["--name", "timing", "--batchSize", "1", "--gpu_ids", "-1", "--load_size", str(size), "--crop_size", str(size),
+                    "--checkpoints_dir", ck] + list(R.README_TRAIN_FLAGS)
+            opt = R.reference_options(argv, train=True)
+            torch.manual_seed(0)
+            with contextlib.redirect_stdout(sys.stderr):
+                trainer = Pix2PixTrainer(opt)
+            data = synth_loader_batch(1, size, seed=1234)
+            secs = 0.0
+            for it in range(2):                                             # 1 warm-up + 1 timed
+                random.seed(it)
+                t0 = time.perf_counter()
+                with contextlib.redirect_stdout(sys.stderr):
+                    trainer.run_generator_one_step(dict(data))
+                    trainer.run_discriminator_one_step(dict(data))
+                secs = time.perf_counter() - t0
+            return secs
+    what = "unmodified reference trainer (G step + D step, README flags + --no_lab_loss, fp32), bs=1"
+    small = min(256, full_size)
+    secs = run(small)
+    ratio = (full_size / small) ** 2
+    if small == full_size or secs * ratio * 2 > budget_s:
+        out = (1 / (secs * ratio), f"{what} at {small}x{small}, 1 timed iteration after 1 warm-up: {secs:.1f} s, scaled x{ratio:.0f} pixels to {full_size}x{full_size}")
+    else:
+        secs = run(full_size)
+        out = (1 / secs, f"{what} at {full_size}x{full_size}, 1 timed iteration after 1 warm-up: {secs:.1f} s")
+    print(json.dumps({"ips": out[0], "threads": threads, "what": out[1]}))

@@ -17,6 +17,13 @@ env: MG_TEST_BACKEND = nccl (default with a GPU) | gloo (CPU: contract emulator 
 """
 import os
 import random
+
+
+def _seed(v):
+    """random.seed on this rank AND the data-parallel shared RNG (michigan_amd.parallel.seed_shared_rng)."""
+    from michigan_amd import parallel
+    parallel.seed_shared_rng(v)
+
 import sys
 
 import numpy as np
@@ -96,7 +103,10 @@ def main(mode):
     assert cfg["n"] % world == 0
     per = cfg["n"] // world
     torch.manual_seed(rank)                                    # different initial weights per rank: the broadcast has to align them
-    opt = TP.repo_options(cfg, gpu_ids=[local] if device.type == "cuda" else [], compute_dtype="fp32")
+    bf16 = mode == "repo_bf16"                                # the benchmarked dtype: 3 steps, collective counts per step, replica equality
+    if bf16:
+        mode, cfg = "repo", dict(cfg, iters=3)
+    opt = TP.repo_options(cfg, gpu_ids=[local] if device.type == "cuda" else [], compute_dtype="bf16" if bf16 else "fp32")
     if mode == "repo":
         trainer = Pix2PixTrainer(opt)
         assert trainer.optimizer_G.dp
@@ -105,17 +115,18 @@ def main(mode):
         trainer = RefLikeTrainer(opt, device)
         assert len(trainer.pix2pix_model.grad_averagers) == 2
     assert parallel.world_size() == world and ops.SYNC_BN_GROUP is parallel.bn_group()
-    assert os.environ.get("MG_DP_ONE_GROUP") == "1" or parallel.bn_group() is not parallel.grad_group()
+    assert (parallel.bn_group() is not parallel.grad_group()) == (os.environ.get("MG_DP_TWO_GROUPS") == "1")    # the second communicator is opt-in
     TP.load_weights(trainer, cfg)
     parallel.reset_collective_counts()
-    rec = {}
+    rec, per_step = {}, []
     for it in range(cfg["iters"]):
+        before = dict(parallel.COLLECTIVES)
         data = synth_loader_batch(cfg["n"], cfg["crop"], seed=cfg["seed_x"] + it)
         cut = lambda v: v[rank * per:(rank + 1) * per]
         mine = lambda: {k: (cut(v).to(device).clone() if torch.is_tensor(v) else cut(v)) for k, v in data.items()}
-        random.seed(cfg["seed_py"] + 2 * it)
+        _seed(cfg["seed_py"] + 2 * it)
         trainer.run_generator_one_step(mine())
-        random.seed(cfg["seed_py"] + 2 * it + 1)
+        _seed(cfg["seed_py"] + 2 * it + 1)
         trainer.run_discriminator_one_step(mine())
         losses = trainer.get_latest_losses()
         vec = torch.stack([losses[k].detach().float().mean() for k in TP.LOSS_KEYS]).to(device)
@@ -124,6 +135,13 @@ def main(mode):
             rec["it%d.loss.%s" % (it, k)] = np.array(v)
         if it == 0:
             rec["it0.generated"] = trainer.get_latest_generated().detach().float().cpu().numpy()
+        per_step.append({k: parallel.COLLECTIVES[k] - before[k] for k in before})
+    # one G+D step issues 28 forward sync-BN all-reduces (7 block inputs + 7 norm_1 inputs, x 2 generator passes), 14 backward ones (a SPADE
+    # pair's two branches share one) and a handful of gradient collectives (arena buckets + one gathered buffer per optimiser; 8 at the
+    # benchmarked size) -- every step the same, on every rank
+    for c_ in per_step:
+        assert c_["syncbn_fwd"] == 28 and c_["syncbn_bwd"] == 14 and 0 < c_["grad_bucket"] <= 8, per_step
+    assert all(c_ == per_step[-1] for c_ in per_step[1:]), per_step           # (step 0 records the gradient-slot layout)
     m = trainer.pix2pix_model_on_one_gpu
     gsd, dsd = m.netG.state_dict(), m.netD.state_dict()
     for k in TP.G_WEIGHTS + TP.G_BUFFERS:
@@ -138,8 +156,12 @@ def main(mode):
     class _G(dict):
         files = property(lambda self: list(self.keys()))
     hip = device.type == "cuda"
-    TP.compare(rec, _G(gold), rtol_loss0=5e-4 if hip else 2e-4, rtol_later=TP.RTOL_LATER_HIP if hip else 1e-2, atol_img=1e-3 if hip else 2e-4,
-               atol_weight=2 * 4e-4 * 2 + 1e-5)
+    if not bf16:
+        TP.compare(rec, _G(gold), rtol_loss0=5e-4 if hip else 2e-4, rtol_later=TP.RTOL_LATER_HIP if hip else 1e-2, atol_img=1e-3 if hip else 2e-4,
+                   atol_weight=2 * 4e-4 * 2 + 1e-5)
+    else:
+        for k in TP.LOSS_KEYS:                                  # bf16 tracks the fp32 goldens loosely (tests/test_gpu_trainer.py); here: finite and sane
+            assert np.isfinite(rec["it2.loss.%s" % k]), k
 
     # replicas bitwise identical
     for net in (m.netG, m.netD):
@@ -151,7 +173,7 @@ def main(mode):
     assert c["syncbn_fwd"] > 0 and c["syncbn_bwd"] > 0 and 0 < c["grad_bucket"] <= 16 * cfg["iters"], c
     dist.barrier()
     if rank == 0:
-        print("DP_WORKER_OK mode=%s world=%d backend=%s collectives=%s" % (mode, world, backend, dict(c)), flush=True)
+        print("DP_WORKER_OK mode=%s%s world=%d backend=%s collectives=%s per_step=%s" % (mode, "_bf16" if bf16 else "", world, backend, dict(c), per_step[-1]), flush=True)
     dist.destroy_process_group()
 
 

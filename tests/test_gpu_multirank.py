@@ -3,7 +3,7 @@
   * N = 2 ranks over RCCL -- enables itself wherever `torch.cuda.device_count() >= 2` (skipped, not failed, on a one-GPU box):
     tests/dp_worker.py under `python -m torch.distributed.run --nproc-per-node 2`, one sample of fixture A's batch per rank;
     losses averaged over the ranks, images, updated weights, running statistics and spectral-norm vectors against
-    tests/golden/trainer_A.npz; replicas bitwise identical; sync-BN statistics and gradient buckets on two communicators.
+    tests/golden/trainer_A.npz; replicas bitwise identical; sync-BN statistics and gradient buckets on one communicator (MG_DP_TWO_GROUPS=1: two).
     Both consumers: this repo's trainer (FlatAdam arena reduction) and the reference trainer's flow (DataParallelWithCallback wrap +
     torch.optim.Adam + parallel.GradAverager = what `dropin.install()` gives the reference's own pix2pix_trainer.py).
   * two ranks SHARING the one GPU, collectives over gloo, real kernels (both consumers): runs on every box;
@@ -41,18 +41,33 @@ def test_two_rank_rccl_trainer_matches_reference_golden(hip_backend, mode):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (self-enabling on a multi-GPU node)")
-def test_two_rank_rccl_one_communicator_ab(hip_backend):
-    """MG_DP_ONE_GROUP=1 (sync-BN statistics and gradient buckets on ONE communicator, the round-2 layout) stays correct: the A/B switch."""
-    _launch("repo", 2, 29633, {"MG_DP_ONE_GROUP": "1"})
+def test_two_rank_rccl_two_communicators_ab(hip_backend):
+    """MG_DP_TWO_GROUPS=1 (sync-BN statistics on a second communicator, so that they do not queue behind gradient buckets) stays correct:
+    the opt-in A/B switch for a real multi-GPU node (default: one communicator)."""
+    _launch("repo", 2, 29633, {"MG_DP_TWO_GROUPS": "1"})
 
 
 @pytest.mark.parametrize("mode", ["repo", "reflike"])
 def test_two_ranks_sharing_one_gpu_over_gloo_match_reference_golden(hip_backend, mode):
     """World size 2 on the REAL kernels of a one-GPU box: both ranks drive cuda:0, the collectives travel through gloo (host memory).
     Everything but the transport is the multi-GPU path -- cross-rank batch statistics from the HIP reductions, gradient buckets of the
-    GEMM-order arena (repo) / GradAverager buckets adopted from autograd hooks (reflike), two process groups, the parameter broadcast
+    GEMM-order arena (repo) / GradAverager buckets adopted from autograd hooks (reflike), the parameter broadcast
     from different per-rank initialisations -- against the reference trainer's goldens, replicas bitwise identical."""
     out = _launch(mode, 2, 29635 if mode == "repo" else 29636, {"MG_TEST_BACKEND": "gloo_hip"})
+    assert "world=2" in out
+
+
+def test_two_ranks_sharing_one_gpu_bf16_three_steps_collectives_and_replicas(hip_backend):
+    """the benchmarked dtype through the multi-rank path on real kernels -- bf16, three G+D steps, two ranks sharing
+    cuda:0 over gloo: every step issues exactly 28 forward / 14 backward sync-BN all-reduces and the same handful (<= 8) of gradient
+    collectives, and the replicas' weights, running statistics and spectral-norm vectors are bitwise identical after the third step."""
+    out = _launch("repo_bf16", 2, 29637, {"MG_TEST_BACKEND": "gloo_hip"})
+    assert "world=2" in out and "repo_bf16" in out
+
+
+def test_two_ranks_sharing_one_gpu_two_communicators(hip_backend):
+    """The opt-in second communicator (MG_DP_TWO_GROUPS=1) on the real kernels, ranks sharing the GPU over gloo."""
+    out = _launch("repo", 2, 29638, {"MG_TEST_BACKEND": "gloo_hip", "MG_DP_TWO_GROUPS": "1"})
     assert "world=2" in out
 
 

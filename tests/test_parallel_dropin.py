@@ -13,6 +13,13 @@ group), one parameter broadcast, and a `parallel.GradAverager` on every optimise
 """
 import os
 import random
+
+
+def _seed(v):
+    """random.seed on this rank AND the data-parallel shared RNG (michigan_amd.parallel.seed_shared_rng)."""
+    from michigan_amd import parallel
+    parallel.seed_shared_rng(v)
+
 import socket
 import sys
 
@@ -95,7 +102,7 @@ def _toy_worker(rank, world, port, q, mode):
     if world > 1:
         _join(world, rank, port)
         group = parallel.init()
-        assert group is not None and parallel.bn_group() is not group        # two traffic classes, two process groups
+        assert group is not None and (parallel.bn_group() is not group) == (os.environ.get("MG_DP_TWO_GROUPS") == "1")   # second communicator: opt-in
         parallel.broadcast_parameters(net)
     opt = torch.optim.Adam(net.parameters(), lr=1e-2, betas=(0.0, 0.9))
     other = torch.optim.Adam(net.unused.parameters(), lr=1e-2)                # never armed in this test
@@ -197,7 +204,7 @@ def _flat_worker(rank, world, port, q, overlap):
     res = {"raised": False}
 
     def fwd_bwd(scale):
-        random.seed(100)
+        _seed(100)
         out = G(b["input_ref"], orient_mask=b["orient"], image_ref=b["image_ref"], input_tag=b["input_tag"],
                 noise=b["noise"], image_tag=b["image_tag"])
         ((out * gy).sum() * scale).backward()
@@ -238,6 +245,53 @@ def test_flatadam_gradient_accumulation_without_overlap_matches_single_process()
 def test_flatadam_second_backward_with_overlapped_buckets_raises():
     got = _run(_flat_worker, 2, True)
     assert got[0]["raised"] is True and got[1]["raised"] is True
+
+
+def _late_backward_worker(rank, world, port, q):
+    """a backward pass that reaches a FlatAdam's parameters between step() and the next zero_grad() -- the reference loop
+    back-propagates the generator loss into D after D.step() -- is discardable: no collective, no error, gone at zero_grad()."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    torch.set_num_threads(2)
+    from michigan_amd import _cabi, networks, parallel
+    from michigan_amd.optim import FlatAdam
+    from michigan_amd.synth import synth_batch, synth_state_dict
+    from oracle.cabi_emulator import EmulatorBackend
+    import parity_utils as PU
+    _cabi.set_backend(EmulatorBackend())
+    _join(world, rank, port)
+    group = parallel.init()
+    opt = PU.small_opt(ngf=8, crop_size=64)
+    G = networks.SPADEBGenerator(opt).train()
+    G.load_state_dict(synth_state_dict(G.state_dict(), seed=31, gain=1.0))
+    optim = FlatAdam(G.parameters(), lr=1e-3, betas=(0.0, 0.9), bucket_bytes=1 << 18, group=group)
+    b = {k: v[rank:rank + 1] for k, v in synth_batch(2, 64, seed=17).items()}
+
+    def fwd_bwd():
+        _seed(100)
+        out = G(b["input_ref"], orient_mask=b["orient"], image_ref=b["image_ref"], input_tag=b["input_tag"], noise=b["noise"], image_tag=b["image_tag"])
+        out.float().square().sum().backward()
+    optim.zero_grad()
+    fwd_bwd()
+    optim.step()
+    before = dict(parallel.COLLECTIVES)
+    fwd_bwd()                                          # late: behind step(), before zero_grad()
+    late_collectives = parallel.COLLECTIVES["grad_bucket"] - before["grad_bucket"]
+    optim.zero_grad()                                  # discards it
+    assert float(optim.flat_grad.abs().max()) == 0.0
+    fwd_bwd()
+    optim.step()
+    q.put((rank, {"late_collectives": late_collectives, "weights": optim.flat.numpy().copy()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1500)
+def test_flatadam_backward_between_step_and_zero_grad_is_discarded():
+    import numpy as np
+    got = _run(_late_backward_worker, 2)
+    assert got[0]["late_collectives"] == 0 and got[1]["late_collectives"] == 0
+    assert np.array_equal(got[0]["weights"], got[1]["weights"])
 
 
 # ---- the reference's own trainer through dropin.install() ---------------------------------------------------------------------
@@ -281,7 +335,8 @@ def _ref_trainer_worker(rank, world, port, q):
         if world > 1:
             assert trainer.pix2pix_model.group is not None and len(trainer.pix2pix_model.grad_averagers) == 2
             from michigan_amd import ops
-            assert ops.SYNC_BN_GROUP is parallel.bn_group() and ops.SYNC_BN_GROUP is not parallel.grad_group()
+            assert ops.SYNC_BN_GROUP is parallel.bn_group()
+            assert (ops.SYNC_BN_GROUP is not parallel.grad_group()) == (os.environ.get("MG_DP_TWO_GROUPS") == "1")
             first = next(m.netG.parameters()).detach().clone()
             ref0 = first.clone()
             dist.broadcast(ref0, src=0)
@@ -292,9 +347,9 @@ def _ref_trainer_worker(rank, world, port, q):
             data = synth_loader_batch(cfg["n"], cfg["crop"], seed=cfg["seed_x"] + it)
             per = cfg["n"] // world
             mine = {k: (v[rank * per:(rank + 1) * per].clone() if torch.is_tensor(v) else v[rank * per:(rank + 1) * per]) for k, v in data.items()}
-            random.seed(cfg["seed_py"] + 2 * it)
+            _seed(cfg["seed_py"] + 2 * it)
             trainer.run_generator_one_step(dict(mine))
-            random.seed(cfg["seed_py"] + 2 * it + 1)
+            _seed(cfg["seed_py"] + 2 * it + 1)
             trainer.run_discriminator_one_step(dict(mine))
             for k, v in trainer.get_latest_losses().items():
                 rec["it%d.loss.%s" % (it, k)] = float(v.detach().float().mean())
@@ -341,6 +396,89 @@ def test_reference_trainer_through_dropin_two_ranks_equal_single_process():
     c = got[0]["collectives"]
     assert c["syncbn_fwd"] > 0 and c["syncbn_bwd"] > 0 and c["grad_bucket"] >= 4          # 2 iterations x (G + D) optimiser
     assert single["collectives"] == {"syncbn_fwd": 0, "syncbn_bwd": 0, "grad_bucket": 0}
+
+
+def _job_side_effects_worker(rank, world, port, q, ckdir):
+    """what every rank of a `torchrun train.py` job does identically -- checkpoint writes and data loading -- after
+    dropin.install(): util.save_network writes on rank 0 only (temporary file + rename + barrier), data.create_dataloader shards."""
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    import argparse
+    import types
+    from oracle import ref_harness as R
+    R.setup()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import michigan_amd.dropin as dropin
+    dropin.install(compute_dtype="fp32")
+    assert dist.is_initialized() and dist.get_world_size() == world
+    import util.util as U
+    import data
+    saves = {"n": 0}
+    real_save = torch.save
+
+    def counting_save(obj, f, *a, **k):
+        saves["n"] += 1
+        return real_save(obj, f, *a, **k)
+    torch.save = counting_save
+    net = torch.nn.Linear(5, 3)
+    with torch.no_grad():
+        net.weight.fill_(0.25)                                  # replicas hold identical weights (the wrapper's broadcast)
+        net.bias.fill_(-1.0)
+    opt = argparse.Namespace(checkpoints_dir=ckdir, name="job", gpu_ids=[])
+    for _ in range(3):                                          # repeated saves: every rank passes the barrier every time
+        U.save_network(net, "G", "latest", opt)
+    torch.save = real_save
+    path = os.path.join(ckdir, "job", "latest_net_G.pth")
+    sd = torch.load(path)
+    assert torch.equal(sd["weight"], net.weight.detach()) and torch.equal(sd["bias"], net.bias.detach())
+    assert [f for f in os.listdir(os.path.dirname(path)) if ".tmp." in f] == []
+    assert next(net.parameters()).device.type == "cpu"
+
+    # a dataset the reference's name lookup finds (data/__init__.py:16-38): 37 samples, each its own index
+    from data.base_dataset import BaseDataset
+
+    class ToyDataset(BaseDataset):
+        def initialize(self, opt):
+            self.n = 37
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            return {"idx": i}
+    mod = types.ModuleType("data.toy_dataset")
+    mod.ToyDataset = ToyDataset
+    sys.modules["data.toy_dataset"] = mod
+    seen = {}
+    for serial in (True, False):
+        o = argparse.Namespace(dataset_mode="toy", batchSize=4, serial_batches=serial, nThreads=0, isTrain=True)
+        loader = data.create_dataloader(o)
+        epochs = []
+        for _ in range(2):
+            idx = []
+            for b in loader:
+                assert len(b["idx"]) == 4 // world                # global batch = opt.batchSize, like DataParallel's scatter
+                idx += [int(v) for v in b["idx"]]
+            epochs.append(idx)
+        seen["serial" if serial else "shuffled"] = epochs
+    q.put((rank, {"saves": saves["n"], "seen": seen}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.skipif(not _reference_present(), reason="reference checkout not present")
+def test_dropin_job_side_effects_checkpoint_on_rank0_and_sharded_loader():
+    import tempfile
+    with tempfile.TemporaryDirectory() as ck:
+        got = _run(_job_side_effects_worker, 2, ck, timeout=500)
+    assert got[0]["saves"] == 3 and got[1]["saves"] == 0          # only rank 0 touches the file
+    for kind in ("serial", "shuffled"):
+        for ep in range(2):
+            a, b = got[0]["seen"][kind][ep], got[1]["seen"][kind][ep]
+            assert len(a) == len(b) == 18 and not set(a) & set(b)  # disjoint halves of the 37 samples (drop_last)
+    assert got[0]["seen"]["serial"][0] == list(range(0, 36, 2)) and got[1]["seen"]["serial"][0] == list(range(1, 36, 2))
+    assert got[0]["seen"]["shuffled"][0] != got[0]["seen"]["shuffled"][1]      # the sampler advances its epoch by itself
 
 
 # ---- the GPU suite's multi-rank worker, on gloo ------------------------------------------------------------------------------------

@@ -4,6 +4,13 @@ reproduces the single-process result on the concatenated batch -- the property s
 (sync_batchnorm/batchnorm.py:219-227).  Runs on the C-ABI contract emulator."""
 import os
 import random
+
+
+def _seed(v):
+    """random.seed on this rank AND the data-parallel shared RNG (michigan_amd.parallel.seed_shared_rng)."""
+    from michigan_amd import parallel
+    parallel.seed_shared_rng(v)
+
 import socket
 import sys
 
@@ -49,7 +56,7 @@ def _one_step(rank, world, port, n_total, q, bucket_bytes=1 << 18, sink=None):
     gy = torch.randn(n_total, 3, 128, 128, generator=torch.Generator().manual_seed(5))[rank * per:(rank + 1) * per]
     for it in range(2):
         optim.zero_grad()
-        random.seed(100 + it)
+        _seed(100 + it)
         out = G(b["input_ref"], orient_mask=b["orient"], image_ref=b["image_ref"], input_tag=b["input_tag"],
                 noise=b["noise"], image_tag=b["image_tag"])
         ((out * gy).sum() / per).backward()
@@ -170,7 +177,7 @@ def _trainer_step(rank, world, port, n_total, q):
     full = synth_batch(n_total, 128, seed=23)
     per = n_total // world
     data = {k: v[rank * per:(rank + 1) * per] for k, v in full.items()}
-    random.seed(7)
+    _seed(7)
     tr.optimizer_G.zero_grad()
     tr._set_d_requires_grad(False)
     g_losses, _ = tr.pix2pix_model(data, mode="generator")
