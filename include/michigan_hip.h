@@ -349,7 +349,7 @@ int mg_gabor_argmax_bwd(const float* dconf, const uint8_t* idx, const float* ban
  * (= NHWC with H*W flattened) in `dtype`, rows ld* ELEMENTS apart (ld >= width: q / k / v may be column slices of one fused
  * projection, out the second half of the [x | out] concatenation the reference returns).  Flash-style: the [L, L] score
  * matrix is never materialised (the reference writes it: torch.bmm -> softmax -> torch.bmm); bf16: bf16 MFMA with fp32
- * accumulation, probabilities rounded to bf16 for the second product; fp32: exact-fp32 MFMA throughout.
+ * accumulation, the probabilities enter the second product as hi + lo bf16 pairs (16 mantissa bits); fp32: exact-fp32 MFMA throughout.
  * Built for d_qk = 64, d_v = 256 (SelfAttention(256, downsample 4)); any L, any N <= 65535.
  * ------------------------------------------------------------------------- */
 int mg_self_attention(const void* q, const void* k, const void* v, void* out, int32_t dtype, int32_t N, int32_t L,

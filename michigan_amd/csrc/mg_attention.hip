@@ -16,7 +16,7 @@
 //                      ds_read_b32 (32 lanes = 32 consecutive channels).
 // Online softmax per query column: running max m (synchronised between the two half-waves that share a query), running
 // partial row sum l (added across the halves at the end), O rescaled only when some lane's max moved (wave-uniform branch).
-// bf16: v_mfma_f32_32x32x16_bf16, P rounded to bf16 for the second product (fp32 accumulation everywhere);
+// bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulation everywhere, P enters the second product as a hi + lo pair of bf16 values;
 // fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fma chains: the parity configuration).
 #include "mg_common.h"
 
@@ -195,11 +195,24 @@ __global__ __launch_bounds__(NTHR_A, 1) void self_attention_kernel(const AttnArg
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    // B operand: this lane's 8 keys of the 16-key step {16h + 4hi + 0..3, 16h + 8 + 4hi + 0..3} = accumulators 8h .. 8h+7
-                    uint4 pbw;
-                    pbw.x = f2bf2(s[kt][8 * h + 0], s[kt][8 * h + 1]); pbw.y = f2bf2(s[kt][8 * h + 2], s[kt][8 * h + 3]);
-                    pbw.z = f2bf2(s[kt][8 * h + 4], s[kt][8 * h + 5]); pbw.w = f2bf2(s[kt][8 * h + 6], s[kt][8 * h + 7]);
-                    const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pbw);
+                    // B operand: this lane's 8 keys of the 16-key step {16h + 4hi + 0..3, 16h + 8 + 4hi + 0..3} = accumulators 8h .. 8h+7.
+                    // The probabilities go into the second product as TWO bf16 terms, p = hi + lo (lo = bf16(p - hi): 16 mantissa bits
+                    // together): a single bf16 P (2^-9 per weight, the usual flash-attention choice) made the frozen net's output measurably
+                    // noisier than the reference-shaped softmax in fp32 it replaces (tests/test_inpaint.py bf16 bound); the second MFMA per
+                    // step costs ~0.1 ms per 8-image pass.
+                    uint4 pbw, plw;
+                    {
+                        uint32_t hw[4], lw[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float a0 = s[kt][8 * h + 2 * j], a1 = s[kt][8 * h + 2 * j + 1];
+                            hw[j] = f2bf2(a0, a1);
+                            lw[j] = f2bf2(a0 - __uint_as_float(hw[j] << 16), a1 - __uint_as_float(hw[j] & 0xffff0000u));
+                        }
+                        pbw = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                        plw = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+                    }
+                    const bf16x8_t pb = __builtin_bit_cast(bf16x8_t, pbw), pl = __builtin_bit_cast(bf16x8_t, plw);
                     const int row0 = kt * 32 + 16 * h + 4 * hi + (i16 >> 2);          // a1 reads row0 + 8 (same swizzle: (row0 + 8) & 7 == row0 & 7)
                     const int colb = (g2 & 1) * 16 + (i16 & 3) * 4;                    // channel inside a 32-channel block
                     const unsigned char* vrow = vb + row0 * A::VROW + colb * 2;
@@ -210,6 +223,7 @@ __global__ __launch_bounds__(NTHR_A, 1) void self_attention_kernel(const AttnArg
                         const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp_t)(pa + 8 * A::VROW));
                         const s16x8_t av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                         acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), pb, acc[dt], 0, 0, 0);
+                        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), pl, acc[dt], 0, 0, 0);
                     }
                 }
         } else {

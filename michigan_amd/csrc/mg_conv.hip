@@ -598,7 +598,7 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 19 && (value == 0 || value == 1)) { g_mg_norm_bwd_vec = value; return MG_OK; }
     if (key == 7 && (value == 0 || value == 1)) { g_mg_conv_wide = value; return MG_OK; }
     if (key == 8 && value >= 0 && value <= 2) { g_mg_conv_dot = value; return MG_OK; }
-    if (key == 9 && (value == 3 || value == 4 || value == 5)) { g_mg_conv_halo_ring = value; return MG_OK; }   // 5 = 4 slabs + software-pipelined fragments
+    if (key == 9 && (value == 3 || value == 4)) { g_mg_conv_halo_ring = value; return MG_OK; }
     if (key == 15 && (value == 0 || value == 1)) { g_mg_conv_noxpre = value; return MG_OK; }
     if (key == 13) { g_probe_lo = (unsigned)value; return MG_OK; }
     if (key == 14) { const unsigned long long a = ((unsigned long long)(unsigned)value << 32) | g_probe_lo; const int r = conv_halo_set_probe(a); return r != MG_OK ? r : wgrad3x3_set_probe(a); }

@@ -44,13 +44,7 @@ constexpr int TW = 16, PW = TW + 2;
 // busy: the waves wait for the LDS-DMA weight stream, so the prefetch distance grows by one tap.  The fourth 8 KiB slab fits
 // next to two workgroups per CU only if the patch stage stops being rounded up to a multiple of four 1 KiB blocks (21 -> 24
 // at 16x16 pixels): the spare DMA instructions that keep every wave's load count equal now land in one shared 1 KiB dump block.
-// RING 5 = the 4-slab ring with SOFTWARE-PIPELINED operand fragments (round 4): the fragments of K step q + 1 are read from LDS before the
-// MFMAs of step q are issued (two fragment sets in registers) and the per-tap wait + barrier + DMA issue sits in the MIDDLE of a tap,
-// between its two K steps, where it makes tap g + 1's weights visible for the prefetch -- a wave whose partner workgroup is in its
-// prologue / epilogue (28 % of a short-K workgroup's life, profiles/r02_halo_probe.txt) then keeps the matrix pipe fed by itself
-// instead of idling for an LDS round trip after every eighth MFMA.
-template <int WM, int NT, int RING_ = 3> struct HaloGeom {
-    static constexpr int RING = RING_ == 5 ? 4 : RING_;
+template <int WM, int NT, int RING = 3> struct HaloGeom {
     static constexpr int WN = 4 / WM;
     static constexpr int TM = WM * 64;
     static constexpr int TH = WN * NT * 32 / TW;                // 8 or 16
@@ -79,12 +73,10 @@ __device__ __forceinline__ unsigned long long stamp()
     return v;
 }
 
-template <typename T, int EPI, int WM, int NT, int RING_ = 3, int PROBE = 0>
+template <typename T, int EPI, int WM, int NT, int RING = 3, int PROBE = 0>
 __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(const ConvK d)
 {
-    using G = HaloGeom<WM, NT, RING_>;
-    constexpr bool PIPE = RING_ == 5;
-    constexpr int RING = G::RING;
+    using G = HaloGeom<WM, NT, RING>;
     constexpr int PF = RING - 1;                               // weight slabs in flight ahead of the tap being computed
     constexpr int MT = 2, WN = G::WN;
     constexpr int TH = G::TH, PROWS = G::PROWS, PSTAGE = G::PSTAGE, ASTAGE = G::ASTAGE, TM_H = G::TM;
@@ -163,7 +155,7 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
 
     // The product bf16 kernel never zeroes its accumulators: the first tap's first K step runs its MFMAs with a constant-zero C
     // operand (128 v_mov per lane less in a prologue whose VALU issue competes with the co-resident workgroup's MFMA stream).
-    constexpr bool ZERO_C = BF && RING == 3 && !PIPE && (PROBE == 0 || PROBE == 4);
+    constexpr bool ZERO_C = BF && RING == 3 && (PROBE == 0 || PROBE == 4);
     f32x16_t acc[MT][NT];
     if constexpr (!ZERO_C) {
 #pragma unroll
@@ -191,21 +183,6 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
                 boff[t][nt] = G::PATCH0 + brow * ROWB + ((ksp ^ ((brow >> 2) & 3)) << 4);
             }
         }
-    }
-
-    // PIPE: the 36 hoisted patch offsets are the largest block of address registers; relative to PATCH0 they fit 16 bits (two patch stages
-    // = 42 KiB), so two column tiles share a register (the ds_read's immediate offset carries PATCH0) -- the 18 registers freed pay for the
-    // second fragment set.
-    typedef __attribute__((ext_vector_type(2))) unsigned short u16x2_t;
-    u16x2_t bpk[9][NT / 2];
-    if constexpr (PIPE) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int j = 0; j < NT / 2; ++j) {
-                bpk[t][j][0] = (unsigned short)(boff[t][2 * j] - G::PATCH0);
-                bpk[t][j][1] = (unsigned short)(boff[t][2 * j + 1] - G::PATCH0);
-            }
     }
 
     auto compute = [&](auto t_, int slot, auto first_) {
@@ -287,7 +264,7 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
     // SPADE (bf16): the x quads the epilogue modulates are fetched HERE, ahead of every operand load, so they arrive in the shadow
     // of the first patch instead of costing the epilogue its own trip to HBM with the matrix pipe idle behind it (the SPADE epilogue
     // was 8.2 us of a 39 us workgroup, 6.3 us of it with the stores predicated off: profiles/r02_halo_probe.txt).  32 registers.
-    constexpr bool XPRE = EPI == MG_EPI_SPADE && BF && !PIPE;       // (PIPE spends those 32 registers on the second fragment set)
+    constexpr bool XPRE = EPI == MG_EPI_SPADE && BF;
     uint2 xpre[2 * NT * 2] = {};
     bool xpre_ok = false;
     if constexpr (XPRE) {
@@ -390,77 +367,6 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
         };
         chunk(0, std::true_type{});
         for (int c = 1; c < nchunk; ++c) chunk(c, std::false_type{});
-    } else if constexpr (PIPE) {
-        static_assert(BF && RING == 4, "pipelined fragments: bf16, 4-slab ring");
-        struct Frag { bf16x8_t a[MT], b[NT]; };
-        Frag f0, f1;
-        auto load_frags = [&](Frag& f, auto t_, int slot, auto ks_) {
-            constexpr int t = decltype(t_)::value, ks = decltype(ks_)::value;
-            const unsigned char* As = smem + slot * ASTAGE;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                f.a[mt] = *reinterpret_cast<const bf16x8_t*>(As + mt * 32 * ROWB + (ks ? aoff ^ KX : aoff));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const unsigned rel = bpk[t][nt >> 1][nt & 1];
-                f.b[nt] = *reinterpret_cast<const bf16x8_t*>(smem + G::PATCH0 + (ks ? rel ^ KX : rel));
-            }
-        };
-        auto mfmas = [&](const Frag& f, auto first_) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if constexpr (decltype(first_)::value) {
-                        const f32x16_t zero = {};
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mt], f.b[nt], zero, 0, 0, 0);
-                    } else
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mt], f.b[nt], acc[mt][nt], 0, 0, 0);
-                }
-        };
-        // Load order per wave: params, patch(0), W(0), W(1), W(2) | mid-tap g: W(g+3) [, patch(c+1) at t = 0].  Tap g = 9 c + t lives in slot g & 3.
-        // prologue sync: patch(0) and W(0) landed (younger: W(1), W(2)), visible to every wave; first fragments
-        wait_vmcnt<2 * A_IPS>();
-        __builtin_amdgcn_s_barrier();
-        int s0 = 0;                                               // slot of tap 0 of this chunk
-        load_frags(f0, std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{});
-        auto chunk = [&](int c, auto first_) {
-            const bool next_chunk = (c + 1 < nchunk);
-            const int pdelta = (c & 1) ? -PSTAGE : PSTAGE;
-            static_for<0, 9>([&](auto t_) {
-                constexpr int t = decltype(t_)::value;
-                // [A] second K step's fragments of this tap (same slot: already visible), [B] first K step's MFMAs
-                load_frags(f1, t_, (s0 + t) & 3, std::integral_constant<int, 1>{});
-                {                                                            // both K steps of tap t are in registers: its addresses move to the next chunk's patch
-                    const u16x2_t pd = {(unsigned short)pdelta, (unsigned short)pdelta};     // +- PSTAGE mod 2^16 per half (v_pk_add_u16)
-#pragma unroll
-                    for (int j = 0; j < NT / 2; ++j) bpk[t][j] += pd;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                mfmas(f0, std::bool_constant<ZERO_C && decltype(first_)::value && t == 0>{});
-                __builtin_amdgcn_sched_barrier(0);
-                // [C] tap g + 1's weights: landed (younger loads: W(g+2) and, behind a chunk start, the next chunk's patch) and visible; the slot of
-                //     tap g - 1 is free for W(g+3)
-                const bool has1 = t < 8 || next_chunk, has2 = t < 7 || next_chunk, has3 = t < 6 || next_chunk;
-                if (has1) {
-                    if constexpr (t == 1 || t == 2) { if (next_chunk) wait_vmcnt<A_IPS + P_IPS>(); else if (has2) wait_vmcnt<A_IPS>(); else wait_vmcnt<0>(); }
-                    else                            { if (has2) wait_vmcnt<A_IPS>(); else wait_vmcnt<0>(); }
-                    __builtin_amdgcn_s_barrier();
-                    if (has3) issue_a((s0 + t + 3) & 3, t == 5);
-                    if constexpr (t == 0) { if (next_chunk) issue_patch((c + 1) & 1); }
-                    // [D] first K step's fragments of the NEXT tap (t = 8: tap 0 of the next chunk, whose slot is s0 + 9 = s0 + 1 and whose patch
-                    //     addresses boff[0] were advanced at this chunk's tap 0)
-                    if constexpr (t < 8) load_frags(f0, std::integral_constant<int, t + 1>{}, (s0 + t + 1) & 3, std::integral_constant<int, 0>{});
-                    else                 load_frags(f0, std::integral_constant<int, 0>{}, (s0 + 9) & 3, std::integral_constant<int, 0>{});
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // [E] second K step's MFMAs
-                mfmas(f1, std::false_type{});
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            s0 = (s0 + 1) & 3;
-        };
-        for (int c = 0; c < nchunk; ++c) chunk(c, std::false_type{});      // (no peeled first chunk: it cost 22 spilled registers)
     } else {
         // RING 4: tap g = 9 c + t lives in slot g & 3 (9 = 1 mod 4, so the slot of tap t moves by one per chunk: a scalar).
         // Issue order per wave: ... W(g+1) W(g+2) | tap g: wait W(g), barrier, issue W(g+3) [, patch(c+1) at t = 0], compute.
@@ -548,7 +454,6 @@ int launch_halo(ConvK& k, hipStream_t st)
             }
             if (g_mg_conv_dbg_noepi >= 5) return launch_halo_g<T, EPI, 2, 4, 3, 4>(k, st);      // 6: ... with the stores predicated off
         }
-        if constexpr (sizeof(T) == 2) { if (g_mg_conv_halo_ring == 5) return launch_halo_g<T, EPI, 2, 4, 5>(k, st); }
         return g_mg_conv_halo_ring == 4 ? launch_halo_g<T, EPI, 2, 4, 4>(k, st) : launch_halo_g<T, EPI, 2, 4, 3>(k, st);
     }
     return launch_halo_g<T, EPI, 2, 2>(k, st);

@@ -1204,7 +1204,7 @@ def test_self_attention_matches_contract(hip_backend, dt):
     [q | k | v] projection, and the output written into the second half of a wider buffer."""
     from michigan_amd import ops
     g = torch.Generator().manual_seed(21)
-    tol = 2e-5 if dt == "f32" else 2.0 ** -7
+    tol = 2e-5 if dt == "f32" else 2.0 ** -8           # bf16: the output's own rounding (the probabilities carry 16 mantissa bits)
     for (n, L, scale, fused) in ((2, 4096, 0.35, False), (1, 256, 1.0, False), (3, 200, 0.5, True), (1, 333, 1.5, False), (2, 64, 0.2, True)):
         q = (torch.randn(n, L, 64, generator=g) * scale).to(DT[dt])
         k = (torch.randn(n, L, 64, generator=g) * scale).to(DT[dt])
