@@ -138,9 +138,9 @@ int64_t mg_wgrad_det_workspace(const mg_wgrad_desc* d);
 
 /* ---------------------------------------------------------------------------
  * Per-channel statistics (sync-BN / instance-norm reduce).
- *   x is [G][P][C]; sums[g][0][c] = sum_p x, sums[g][1][c] = sum_p x*x  (fp64: the reduction accumulates the
- *   shifted values x - x[g][0][c] in fp32 per thread, adds the partial sums in fp64 and un-shifts in fp64, so that
- *   var = E[x^2] - E[x]^2 in mg_norm_finalize carries no fp32 cancellation; the cross-rank all-reduce adds fp64 sums).
+ *   x is [G][P][C]; sums[g][0][c] = sum_p x, sums[g][1][c] = sum_p x*x  (fp64: every thread accumulates its values in
+ *   double from the first add, partial sums and sums stay fp64, so that var = E[x^2] - E[x]^2 in mg_norm_finalize carries
+ *   no fp32 cancellation; the cross-rank all-reduce adds fp64 sums).
  *   G = 1, P = N*H*W for batch norm (sync_batchnorm/batchnorm.py:63-68,128-145:
  *   F.batch_norm on one device, sum/ssum reduce on several); G = N, P = H*W for
  *   nn.InstanceNorm2d (normalization.py:47-48, encoder.py:173-181).

@@ -17,7 +17,6 @@
 
 int g_mg_conv_splitk_wide = 0;   // ... also for launches of 161..320 workgroups with >= 256 K steps (mg_set_option(17, 1)): measured flat, off
 int g_mg_conv_splitk = 1;        // deterministic split-K for low-resolution long-K layers (mg_set_option(5, v))
-int g_mg_conv_halo_ring = 3;     // weight-slab ring of the big halo tile: 3 = two taps in flight, 4 = three (mg_set_option(9, v)); measured equal (profiles/r02_halo_ring_ab.txt)
 int g_mg_conv_halo_big = 1;      // 128 channels x 16x16 pixel halo tiles where the launch is big enough (mg_set_option(4, v))
 int g_mg_conv_halo = 1;          // 3x3 stride-1 convs on the LDS halo-tile kernel (mg_set_option(2, v))
 int g_mg_conv_bigtiles = 1;      // allow the 128x256 / 256x256 tiles (mg_set_option(1, v))
@@ -598,11 +597,14 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 19 && (value == 0 || value == 1)) { g_mg_norm_bwd_vec = value; return MG_OK; }
     if (key == 7 && (value == 0 || value == 1)) { g_mg_conv_wide = value; return MG_OK; }
     if (key == 8 && value >= 0 && value <= 2) { g_mg_conv_dot = value; return MG_OK; }
-    if (key == 9 && (value == 3 || value == 4)) { g_mg_conv_halo_ring = value; return MG_OK; }
+#if MG_PROBES
+    // measurement builds only (python tools/build_variant.py probes mg_conv.hip mg_conv_halo.hip mg_wgrad3x3.hip -DMG_PROBES=1): truncated /
+    // stamped variants of the big halo tile and of wgrad3x3_kernel, their stamp buffer, the SPADE x prefetch off
     if (key == 15 && (value == 0 || value == 1)) { g_mg_conv_noxpre = value; return MG_OK; }
     if (key == 13) { g_probe_lo = (unsigned)value; return MG_OK; }
     if (key == 14) { const unsigned long long a = ((unsigned long long)(unsigned)value << 32) | g_probe_lo; const int r = conv_halo_set_probe(a); return r != MG_OK ? r : wgrad3x3_set_probe(a); }
     if (key == 12 && (value == 0 || value == 1)) { g_mg_wgrad3x3_probe = value; return MG_OK; }
     if (key == 10 && value >= 0 && value <= 6) { g_mg_conv_dbg_noepi = value; return MG_OK; }
+#endif
     return mg_fail(MG_ERR_ARG, "mg_set_option: unknown key/value %d/%d", key, value);
 }

@@ -2,6 +2,9 @@
 // mg_conv.hip, 3x3 halo-tile kernel in mg_conv_halo.hip).  Everything here is static / inline: the
 // library is built without relocatable device code, so each TU carries its own copy.
 #pragma once
+#ifndef MG_PROBES
+#define MG_PROBES 0        // 1: measurement builds (stamped / truncated kernel variants + their mg_set_option keys); tools/build_variant.py
+#endif
 #include "mg_common.h"
 #include <type_traits>
 

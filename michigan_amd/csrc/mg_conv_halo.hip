@@ -33,34 +33,33 @@
 
 extern int g_mg_conv_halo_big;     // mg_set_option(4, v): 0 = never use the 128 x 16x16 geometry
 extern int g_mg_conv_dbg_noepi;    // mg_set_option(10, v): 0 product; 1 main loop only; 2..4 probes of the big tile (below)
-extern int g_mg_conv_halo_ring;    // mg_set_option(9, v): weight-slab ring depth of the 128 x 16x16 geometry (3 or 4)
 
 namespace {
 
 constexpr int TW = 16, PW = TW + 2;
 
-// RING = weight slabs in flight + 1.  RING 3: one tap computing, two fetching (the round-1 kernel).  RING 4: three fetching --
-// PMC on the SPADE shape (profiles/r01_pmc_halo_final.txt) put 37 % of the wave cycles in s_waitcnt with the LDS pipe only 22 %
-// busy: the waves wait for the LDS-DMA weight stream, so the prefetch distance grows by one tap.  The fourth 8 KiB slab fits
-// next to two workgroups per CU only if the patch stage stops being rounded up to a multiple of four 1 KiB blocks (21 -> 24
-// at 16x16 pixels): the spare DMA instructions that keep every wave's load count equal now land in one shared 1 KiB dump block.
-template <int WM, int NT, int RING = 3> struct HaloGeom {
+// Weight ring: three 8 KiB slabs, one tap computing and two fetching.  (A fourth slab -- three taps in flight -- measured equal twice,
+// profiles/r02_halo_ring_ab.txt, profiles/r04_halo_pipe_ab.txt, and was removed in round 4 together with the dump block it needed.)
+constexpr int RING = 3;
+template <int WM, int NT> struct HaloGeom {
     static constexpr int WN = 4 / WM;
     static constexpr int TM = WM * 64;
     static constexpr int TH = WN * NT * 32 / TW;                // 8 or 16
     static constexpr int PROWS = (TH + 2) * PW;
     static constexpr int PBLK_REAL = (PROWS + 15) / 16;         // 1 KiB blocks (16 rows of 64 B) the patch really has
     static constexpr int PBLK = (PBLK_REAL + 3) / 4 * 4;        // DMA instructions issued: the same count by every wave
-    static constexpr bool DUMP = RING > 3 && PBLK != PBLK_REAL; // spare instructions write a shared dump block instead of padding each stage
-    static constexpr int PSTAGE = (DUMP ? PBLK_REAL : PBLK) * 1024;
+    static constexpr int PSTAGE = PBLK * 1024;
     static constexpr int ASTAGE = TM * ROWB;
     static constexpr int A_IPS = TM / 64, P_IPS = PBLK / 4;
     static constexpr int PATCH0 = RING * ASTAGE;                 // byte offset of the first patch stage
-    static constexpr int DUMP_OFF = PATCH0 + 2 * PSTAGE;
-    static constexpr int PAR = DUMP_OFF + (DUMP ? 1024 : 0);     // epilogue channel parameters (2*TM floats)
+    static constexpr int PAR = PATCH0 + 2 * PSTAGE;              // epilogue channel parameters (2*TM floats)
     static constexpr int LDS = PAR + 2 * TM * 4;
     static constexpr int OCC = NT == 4 ? 2 : 3;                 // waves per SIMD the register budget is set for
 };
+
+#ifndef MG_PROBES
+#define MG_PROBES 0              // 1: also build the stamped / truncated measurement variants of the big tile (tools/probe_halo.py via tools/build_variant.py)
+#endif
 
 // PROBE (measurement builds of the big tile, mg_set_option(10, 2..4); results are WRONG, only the time / the stamps mean anything):
 //   1 = no weight stream after the prologue, 2 = no s_barrier, 3 = s_memtime stamps around the wait, the barrier and the tap
@@ -73,10 +72,10 @@ __device__ __forceinline__ unsigned long long stamp()
     return v;
 }
 
-template <typename T, int EPI, int WM, int NT, int RING = 3, int PROBE = 0>
+template <typename T, int EPI, int WM, int NT, int PROBE = 0>
 __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(const ConvK d)
 {
-    using G = HaloGeom<WM, NT, RING>;
+    using G = HaloGeom<WM, NT>;
     constexpr int PF = RING - 1;                               // weight slabs in flight ahead of the tap being computed
     constexpr int MT = 2, WN = G::WN;
     constexpr int TH = G::TH, PROWS = G::PROWS, PSTAGE = G::PSTAGE, ASTAGE = G::ASTAGE, TM_H = G::TM;
@@ -86,7 +85,7 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
     constexpr int CH  = ROWB / (int)sizeof(T);
     constexpr int KX  = BF ? 32 : 16;                          // byte XOR that selects the lane's second K piece
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring RING x ASTAGE][patch 2 x PSTAGE][dump][params]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [ring RING x ASTAGE][patch 2 x PSTAGE][params]
     unsigned long long e_entry = 0;
     if constexpr (PROBE == 4) e_entry = stamp();
 
@@ -140,8 +139,7 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
 #pragma unroll
         for (int j = 0; j < P_IPS; ++j) {
             const int blk = wave + 4 * j;
-            const unsigned dst = (G::DUMP && blk >= G::PBLK_REAL) ? lds0 + G::DUMP_OFF : base + blk * 1024;   // rows past the patch fetch zeros
-            glds16(pp[j], __builtin_amdgcn_readfirstlane(dst));
+            glds16(pp[j], __builtin_amdgcn_readfirstlane(base + blk * 1024));                                  // rows past the patch fetch zeros
             pp[j] += ROWB;
         }
     };
@@ -155,7 +153,7 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
 
     // The product bf16 kernel never zeroes its accumulators: the first tap's first K step runs its MFMAs with a constant-zero C
     // operand (128 v_mov per lane less in a prologue whose VALU issue competes with the co-resident workgroup's MFMA stream).
-    constexpr bool ZERO_C = BF && RING == 3 && (PROBE == 0 || PROBE == 4);
+    constexpr bool ZERO_C = BF && (PROBE == 0 || PROBE == 4);
     f32x16_t acc[MT][NT];
     if constexpr (!ZERO_C) {
 #pragma unroll
@@ -344,7 +342,7 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
             if (keep == 12345.678f) reinterpret_cast<T*>(d.out)[1 << 20] = (T)1;
             return;
         }
-    } else if constexpr (RING == 3) {
+    } else {
         auto chunk = [&](int c, auto first_) {
             const bool next_chunk = (c + 1 < nchunk);
             const int pdelta = (c & 1) ? -PSTAGE : PSTAGE;          // this tap's patch addresses for the next chunk
@@ -367,38 +365,14 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
         };
         chunk(0, std::true_type{});
         for (int c = 1; c < nchunk; ++c) chunk(c, std::false_type{});
-    } else {
-        // RING 4: tap g = 9 c + t lives in slot g & 3 (9 = 1 mod 4, so the slot of tap t moves by one per chunk: a scalar).
-        // Issue order per wave: ... W(g+1) W(g+2) | tap g: wait W(g), barrier, issue W(g+3) [, patch(c+1) at t = 0], compute.
-        // Loads younger than W(g) when tap g waits: W(g+1), W(g+2) (those that exist) and, at t = 1..3, the next chunk's patch.
-        int s0 = 0;                                               // slot of tap 0 of this chunk
-        for (int c = 0; c < nchunk; ++c) {
-            const bool next_chunk = (c + 1 < nchunk);
-            const int pdelta = (c & 1) ? -PSTAGE : PSTAGE;
-            static_for<0, 9>([&](auto t_) {
-                constexpr int t = decltype(t_)::value;
-                if (next_chunk) {
-                    if constexpr (t >= 1 && t <= 3) wait_vmcnt<2 * A_IPS + P_IPS>(); else wait_vmcnt<2 * A_IPS>();
-                } else {
-                    if constexpr (t <= 6) wait_vmcnt<2 * A_IPS>(); else if constexpr (t == 7) wait_vmcnt<A_IPS>(); else wait_vmcnt<0>();
-                }
-                __builtin_amdgcn_s_barrier();
-                // weights three taps ahead into the slot that was consumed at the previous tap
-                if constexpr (t < 6) issue_a((s0 + t + 3) & 3, t == 5);
-                else { if (next_chunk) issue_a((s0 + t + 3) & 3, false); }
-                if constexpr (t == 0) { if (next_chunk) issue_patch((c + 1) & 1); }
-                compute(t_, (s0 + t) & 3, std::false_type{});
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) boff[t][nt] += pdelta;
-            });
-            s0 = (s0 + 1) & 3;
-        }
     }
 
+#if MG_PROBES
     if (PROBE != 4 && (d.wide & 2)) {                            // measurement aid (mg_set_option(10, 1)): main loop only; one store keeps the MFMAs alive
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<T*>(d.out)[0] = (T)1;
         return;
     }
+#endif
     if constexpr (PROBE == 4) {
         const unsigned long long e0 = stamp();
         unsigned long long ts[12] = {};
@@ -419,20 +393,19 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
     conv_epilogue<T, MT, NT, EPI, TM_H>(d, acc, m0, pixmap, wm, wn, l31, hi, par, EpiNoMark(), xpre, xpre_ok);
 }
 
-template <typename T, int EPI, int WM, int NT, int RING = 3, int PROBE = 0>
+template <typename T, int EPI, int WM, int NT, int PROBE = 0>
 int launch_halo_g(ConvK& k, hipStream_t st)
 {
-    using G = HaloGeom<WM, NT, RING>;
+    using G = HaloGeom<WM, NT>;
     k.tiles_m = (k.Cout_gemm + G::TM - 1) / G::TM;
     k.tiles_y = (k.Hin + G::TH - 1) / G::TH;
     k.tiles_x = (k.Win + TW - 1) / TW;
     const long nblk = (long)k.N * k.tiles_y * k.tiles_x * k.tiles_m;
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_taps(halo): bad grid %ld", nblk);
-    static_assert(RING == 3 || 2 * G::LDS <= 160 * 1024, "LDS budget of the deep ring: two workgroups per CU");
-    auto kern = conv3x3_halo_kernel<T, EPI, WM, NT, RING, PROBE>;
+    auto kern = conv3x3_halo_kernel<T, EPI, WM, NT, PROBE>;
     if constexpr (G::LDS > 65536) {
         static bool attr_done = false;
-        if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); attr_done = true; }
+        if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); attr_done = true; }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NTHR), G::LDS, st, k);
     MG_CHECK_LAUNCH("mg_conv_taps(halo)");
@@ -446,15 +419,17 @@ int launch_halo(ConvK& k, hipStream_t st)
     // 16x16-pixel tiles once they still give every CU its two workgroups at least twice over
     const long big = (long)k.N * ((k.Hin + 15) / 16) * ((k.Win + 15) / 16) * ((k.Cout_gemm + 127) / 128);
     if (g_mg_conv_halo_big && k.Hin >= 16 && big >= 1024) {
+#if MG_PROBES
         if constexpr (sizeof(T) == 2) {
             if constexpr (EPI == MG_EPI_PLAIN) {
-                if (g_mg_conv_dbg_noepi == 2) return launch_halo_g<T, EPI, 2, 4, 3, 1>(k, st);
-                if (g_mg_conv_dbg_noepi == 3) return launch_halo_g<T, EPI, 2, 4, 3, 2>(k, st);
-                if (g_mg_conv_dbg_noepi == 4) return launch_halo_g<T, EPI, 2, 4, 3, 3>(k, st);
+                if (g_mg_conv_dbg_noepi == 2) return launch_halo_g<T, EPI, 2, 4, 1>(k, st);
+                if (g_mg_conv_dbg_noepi == 3) return launch_halo_g<T, EPI, 2, 4, 2>(k, st);
+                if (g_mg_conv_dbg_noepi == 4) return launch_halo_g<T, EPI, 2, 4, 3>(k, st);
             }
-            if (g_mg_conv_dbg_noepi >= 5) return launch_halo_g<T, EPI, 2, 4, 3, 4>(k, st);      // 6: ... with the stores predicated off
+            if (g_mg_conv_dbg_noepi >= 5) return launch_halo_g<T, EPI, 2, 4, 4>(k, st);      // 6: ... with the stores predicated off
         }
-        return g_mg_conv_halo_ring == 4 ? launch_halo_g<T, EPI, 2, 4, 4>(k, st) : launch_halo_g<T, EPI, 2, 4, 3>(k, st);
+#endif
+        return launch_halo_g<T, EPI, 2, 4>(k, st);
     }
     return launch_halo_g<T, EPI, 2, 2>(k, st);
 }

@@ -317,6 +317,7 @@ int launch3(Wg3K& k, hipStream_t st, int* nsplit, bool dry)
     auto kern = wgrad3x3_kernel<MT, NT, W16>;
     static bool attr_done = false;
     if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr_done = true; }
+#if MG_PROBES
     if constexpr (MT == 2 && NT == 2 && !W16) {
         if (g_mg_wgrad3x3_probe) {
             auto pk = wgrad3x3_kernel<MT, NT, W16, true>;
@@ -327,6 +328,7 @@ int launch3(Wg3K& k, hipStream_t st, int* nsplit, bool dry)
             return MG_OK;
         }
     }
+#endif
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), LDS, st, k);
     MG_CHECK_LAUNCH("mg_conv_wgrad(3x3)");
     return MG_OK;

@@ -89,9 +89,10 @@ def drive(trainer, cfg, device="cpu") -> Dict[str, np.ndarray]:
     for it in range(cfg["iters"]):
         data = synth_loader_batch(cfg["n"], cfg["crop"], seed=cfg["seed_x"] + it)
         to = lambda d: {k: (v.to(device).clone() if torch.is_tensor(v) else v) for k, v in d.items()}
-        random.seed(cfg["seed_py"] + 2 * it)                # BackgroundEncode2's random mask growth (encoder.py:288-297)
+        from michigan_amd import parallel
+        parallel.seed_shared_rng(cfg["seed_py"] + 2 * it)   # = random.seed(...) (+ the data-parallel shared RNG): BackgroundEncode2's random mask growth (encoder.py:288-297)
         trainer.run_generator_one_step(to(data))
-        random.seed(cfg["seed_py"] + 2 * it + 1)
+        parallel.seed_shared_rng(cfg["seed_py"] + 2 * it + 1)
         trainer.run_discriminator_one_step(to(data))
         losses = trainer.get_latest_losses()
         for k in LOSS_KEYS:
