@@ -163,7 +163,7 @@ _PROTOS = {
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 _NO_STATUS = {"mg_wgrad_det_workspace", "mg_norm_apply2_supported", "mg_grad_slot_blocks", "mg_pack_job_blocks", "mg_sn_layer_blocks", "mg_stats_workspace", "mg_sizeof_desc", "mg_abi_version", "mg_last_error", "mg_noise_field_len", "mg_bicubic_ksize"}
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmichigan_hip.so")
+LIB_PATH = os.environ.get("MG_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmichigan_hip.so")   # MG_LIB: a measurement variant (tools/build_variant.py)
 
 
 class HipBackend:

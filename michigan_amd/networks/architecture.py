@@ -10,7 +10,7 @@ from .. import ops
 from .layers import FusedReLU, HipConv2d
 from .normalization import SPADE, spade_pair
 
-PAIR_FUSED = __import__("os").environ.get("MG_NO_PAIR") != "1"          # A/B switch (MG_NO_PAIR=1): norm_0 / norm_s of a learned-shortcut block as one autograd node, upsample by index map
+PAIR_FUSED = True          # norm_0 / norm_s of a learned-shortcut block as one autograd node, upsample by index map (eval mode / odd geometries take the separate nodes)
 
 
 class SPADEResnetBlock(nn.Module):

@@ -42,7 +42,7 @@ def spectral_norm(module, name="weight", n_power_iterations=1, eps=1e-12, dim=No
     return module
 
 
-BATCHED = not ops._LEGACY_WEIGHTS           # A/B switch for SpectralPlan (MG_LEGACY_WEIGHTS=1)
+BATCHED = True           # SpectralPlan (False: per-layer compute_weight, the path stand-alone modules and a network's first pass take; tests)
 
 
 class SpectralPlan:

@@ -40,8 +40,7 @@ SYNC_BN_GROUP = None
 SYNC_BN_ASYNC = os.environ.get("MG_SYNCBN_ASYNC", "0") == "1"
 # Weight / bias gradients of convolutions whose parameters live in an optim.FlatAdam arena bypass autograd: the wgrad kernel
 # accumulates into the arena's persistent GEMM-order buffer and one batched launch per optimiser step drains it (optim.py).
-_LEGACY_WEIGHTS = os.environ.get("MG_LEGACY_WEIGHTS") == "1"      # A/B: per-layer pack / spectral norm / unpack paths (round-1 behaviour)
-GRAD_SINK = not _LEGACY_WEIGHTS
+GRAD_SINK = True          # (False: every weight gradient takes the autograd path -- what parameters outside a FlatAdam arena always do; tests)
 # Deterministic weight gradients (MG_DETERMINISTIC=1 or ops.set_deterministic(True)): the wgrad kernels' split-K partial sums go to
 # per-split slabs that a finishing launch adds in a fixed order instead of fp32 atomics (mg_wgrad_desc.det_ws); costs one pass over
 # splits x |dW| per convolution.  Everything else on the path is deterministic already (two-stage reductions, fixed-order split-K forward).
@@ -214,7 +213,7 @@ def pack_weight(w0: torch.Tensor, w1: Optional[torch.Tensor], dtype, rows_p: int
     return dst
 
 
-BATCHED_PACK = not _LEGACY_WEIGHTS          # A/B switch: refresh all packed images of an optimiser arena with one mg_pack_weights launch
+BATCHED_PACK = True          # refresh all packed images of an optimiser arena with one mg_pack_weights launch (False: per-layer mg_pack_weight, as for parameters outside an arena; tests)
 _ARENA_PACK_TABLES = {}      # id(arena) -> (weakref(arena), slots, job table (device), block map (device), nblocks)
 
 

@@ -2,6 +2,7 @@
    1 main loop only | 2 ... without the weight stream | 3 ... without s_barrier | 4 s_memtime stamps per wave:
    cycles parked in the vmcnt wait, in s_barrier, and from the barrier to the end of the tap's MFMA issue."""
 import os, sys
+os.environ.setdefault("MG_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "michigan_amd", "lib", "variants", "lib_probes.so"))   # built with -DMG_PROBES=1: python tools/build_variant.py probes mg_conv.hip mg_conv_halo.hip mg_wgrad3x3.hip -DMG_PROBES=1
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import michigan_amd  # noqa: F401
 import numpy as np

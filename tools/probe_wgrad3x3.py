@@ -2,6 +2,7 @@
 s_memrealtime ticks (10 ns) per stage and wave in the vmcnt wait, the barrier, the DMA issue (with its address arithmetic)
 and the ds_read + MFMA block; K-loop and atomics-epilogue time per workgroup."""
 import os, sys
+os.environ.setdefault("MG_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "michigan_amd", "lib", "variants", "lib_probes.so"))   # built with -DMG_PROBES=1: python tools/build_variant.py probes mg_conv.hip mg_conv_halo.hip mg_wgrad3x3.hip -DMG_PROBES=1
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import michigan_amd  # noqa: F401
 import numpy as np
