@@ -138,9 +138,10 @@ int64_t mg_wgrad_det_workspace(const mg_wgrad_desc* d);
 
 /* ---------------------------------------------------------------------------
  * Per-channel statistics (sync-BN / instance-norm reduce).
- *   x is [G][P][C]; sums[g][0][c] = sum_p x, sums[g][1][c] = sum_p x*x  (fp64: every thread accumulates its values in
- *   double from the first add, partial sums and sums stay fp64, so that var = E[x^2] - E[x]^2 in mg_norm_finalize carries
- *   no fp32 cancellation; the cross-rank all-reduce adds fp64 sums).
+ *   x is [G][P][C]; sums[g][0][c] = sum_p x, sums[g][1][c] = sum_p x*x  (fp64).  With `shift` the per-chunk fp32 partial
+ *   sums are taken of x - x[g][0][c] and un-shifted in fp64 (sum x = s + n k, sum x^2 = ss + 2 k s + n k^2), so that
+ *   var = E[x^2] - E[x]^2 in mg_norm_finalize carries no fp32 cancellation; the cross-rank all-reduce adds fp64 sums.
+ *   shift = 0 is for column sums of zero-mean data (bias gradients).  mg_channel_stats_finalize always shifts.
  *   G = 1, P = N*H*W for batch norm (sync_batchnorm/batchnorm.py:63-68,128-145:
  *   F.batch_norm on one device, sum/ssum reduce on several); G = N, P = H*W for
  *   nn.InstanceNorm2d (normalization.py:47-48, encoder.py:173-181).
@@ -148,7 +149,7 @@ int64_t mg_wgrad_det_workspace(const mg_wgrad_desc* d);
  *   reduction is two-stage and deterministic (no atomics).
  * ------------------------------------------------------------------------- */
 int64_t mg_stats_workspace(int32_t G, int64_t P, int32_t C);
-int mg_channel_stats(const void* x, int32_t dtype, int32_t G, int64_t P, int32_t C,
+int mg_channel_stats(const void* x, int32_t dtype, int32_t G, int64_t P, int32_t C, int32_t shift,
                      double* sums /* [G][2][C] */, void* partial, void* stream);
 /* mg_channel_stats followed by mg_norm_finalize in TWO launches instead of three (stage 2 finalizes): for statistics that need no
  * cross-rank reduction in between (instance norm; batch norm on one GPU).  sums are multiplied by sum_scale before use (4 for the

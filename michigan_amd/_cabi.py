@@ -92,7 +92,7 @@ _PROTOS = {
     "mg_conv_wgrad": ([ctypes.POINTER(WgradDesc), _vp], _i32),
     "mg_wgrad_det_workspace": ([ctypes.POINTER(WgradDesc)], _i64),
     "mg_stats_workspace": ([_i32, _i64, _i32], _i64),
-    "mg_channel_stats": ([_vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp], _i32),
+    "mg_channel_stats": ([_vp, _i32, _i32, _i64, _i32, _i32, _vp, _vp, _vp], _i32),
     "mg_channel_stats_finalize": ([_vp, _i32, _i32, _i64, _i32, _f32, ctypes.c_double, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i32),
     "mg_norm_finalize": ([_vp, _i32, _i32, ctypes.c_double, _f32, _f32, _vp, _vp, _vp, _vp, _vp], _i32),
     "mg_norm_act_fwd": ([_vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _i32, _f32, _vp, _vp], _i32),

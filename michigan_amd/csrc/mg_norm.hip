@@ -8,12 +8,14 @@
 //   stage 1  grid (chunks, G): register accumulation over the block's pixel
 //            chunk, LDS tree across the thread rows -> partial[g][chunk][2][C]
 //   stage 2  fp64 sum over chunks in a fixed order -> sums[g][2][C]
-// Forward statistics (sum x, sum x^2) are accumulated in FP64 from the first add on: every thread converts its values to double (the
-// part's fp64 vector rate is half its fp32 rate and these passes are HBM-bound: ~3 fp64 operations per element use < 20 % of it),
-// partial sums and the per-channel sums stay fp64 through the cross-rank all-reduce into finalize, so var = E[x^2] - E[x]^2 carries
-// 1e-16 (mean^2 / var + 1) instead of the 6e-8 (...) of fp32 sums (sync_batchnorm/batchnorm.py:128-145 is the same one-pass
-// formula on fp32 sums, batchnorm_reimpl.py:18-74 the two-pass yardstick).  A pivot-shifted fp32 variant was tried first and dropped: with a
-// sample as the pivot the partial sums of ZERO-mean data grow like n |pivot| instead of sqrt(n) sigma.
+// Forward statistics (sum x, sum x^2) are conditioned like a two-pass variance: stage 1 accumulates the SHIFTED values x - k[g][c] with
+// the pivot k = x[g][pixel 0][c] (a sample of the channel: sum (x-k)^2 ~ n (var + (mean-k)^2) carries no mean^2 / var cancellation into
+// the fp32 partials), stage 2 adds the partials in fp64, un-shifts in fp64 (sum x = s + n k, sum x^2 = ss + 2 k s + n k^2) and hands FP64
+// sums to the cross-rank all-reduce and to finalize: nothing between the per-thread partials and var = E[x^2] - E[x]^2 is rounded to
+// fp32 (the one-pass fp32 sums were; sync_batchnorm/batchnorm.py:128-145 is that formula, batchnorm_reimpl.py:18-74 the
+// two-pass yardstick).  `shift = 0` (plain column sums of gradients: ops.channel_sums for bias gradients) keeps k = 0: for ZERO-mean data a
+// sample pivot makes the partial sums grow like n |k| instead of sqrt(n) sigma.  Per-thread fp64 accumulation (no pivot needed) was
+// measured too: same results, stats_stage1_vec 17.8 -> 21.7 us per launch (+0.24 ms per step), not kept.
 #include "mg_common.h"
 #include <type_traits>
 
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(NTHR) void reduce_stage1(
     float* __restrict__ partial, int64_t P, int C, int tpr, int rpb, int64_t chunk, int act, float slope,
     int up = 0, int H = 0, int W = 0)
 {
-    __shared__ typename std::conditional<MODE == 0, double, float>::type red[NTHR * 8];
+    __shared__ float red[NTHR * 8];
     const int tid = threadIdx.x;
     const int g = blockIdx.y, ck = blockIdx.x, nchunks = gridDim.x;
     const int c4 = C / 4;
@@ -66,9 +68,10 @@ __global__ __launch_bounds__(NTHR) void reduce_stage1(
         const int qd = qd0 + tq;
         const bool qv = active && qd < c4;
         const int c = (qd < c4 ? qd : 0) * 4;
-        using acc_t = typename std::conditional<MODE == 0, double, float>::type;      // forward statistics: fp64 from the first add
-        acc_t s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+        float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
         f32x4_t mu, rs;
+        f32x4_t kv = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == 0 && up) kv = ET<T>::load4(x + (size_t)g * P * C + c);     // MODE 0: `up` carries the shift flag -- pivot = the group's first pixel
         if (MODE == 1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { mu[j] = mean[(size_t)g * C + c + j]; rs[j] = rstd[(size_t)g * C + c + j]; }
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(NTHR) void reduce_stage1(
                 const f32x4_t xv = ET<T>::load4(x + ox);
                 if (MODE == 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { const double t = (double)xv[j]; s[j] += t; ss[j] += t * t; }
+                    for (int j = 0; j < 4; ++j) { const float t = xv[j] - kv[j]; s[j] += t; ss[j] += t * t; }
                 } else {
                     const f32x4_t dv = ET<T>::load4(dh + o);
                     f32x4_t hv = {1.f, 1.f, 1.f, 1.f};              // h only matters through the sign of the activation's output
@@ -114,14 +117,14 @@ __global__ __launch_bounds__(NTHR) void reduce_stage1(
         for (int j = 0; j < 4; ++j) { red[tid * 8 + j] = s[j]; red[tid * 8 + 4 + j] = ss[j]; }
         __syncthreads();
         if (qv && tr == 0) {
-            acc_t a[8];
+            float a[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] = red[tid * 8 + j];
             for (int r = 1; r < rpb; ++r) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) a[j] += red[(tid + r * tpr) * 8 + j];
             }
-            acc_t* dst = reinterpret_cast<acc_t*>(partial) + ((size_t)g * nchunks + ck) * 2 * C;
+            float* dst = partial + ((size_t)g * nchunks + ck) * 2 * C;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { dst[c + j] = a[j]; dst[C + c + j] = a[4 + j]; }
         }
@@ -350,21 +353,26 @@ __global__ __launch_bounds__(NTHR) void norm_act_fwd_vec(const T* __restrict__ x
     }
 }
 
-// stage 1 of the plain statistics (sum x, sum x^2) with the same chunking as reduce_stage1<T, 0>; fp64 accumulators, fp64 partial[g][chunk][2][C]
+// stage 1 of the plain statistics (sum x, sum x^2) with the same chunking / partial layout as reduce_stage1<T, 0>
 template <typename T, int PIX>
-__global__ __launch_bounds__(NTHR) void stats_stage1_vec(const T* __restrict__ x, double* __restrict__ partial, int64_t P, int C, int64_t chunk)
+__global__ __launch_bounds__(NTHR) void stats_stage1_vec(const T* __restrict__ x, float* __restrict__ partial, int64_t P, int C, int64_t chunk, int shift)
 {
     constexpr int VEC = VT<T>::VEC;
-    __shared__ double red[NTHR * 2 * VEC];
+    __shared__ float red[NTHR * 2 * VEC];
     const int cv = C / VEC, rows = NTHR / cv;
     const int tq = threadIdx.x % cv, tr = threadIdx.x / cv;
     const int g = blockIdx.y, ck = blockIdx.x, nchunks = gridDim.x, c = tq * VEC;
     const int64_t p0 = (int64_t)ck * chunk;
     const int64_t p1 = (p0 + chunk < P) ? p0 + chunk : P;
-    double s[VEC], ss[VEC];
+    float s[VEC], ss[VEC], kv[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { s[j] = 0.0; ss[j] = 0.0; }
+    for (int j = 0; j < VEC; ++j) { s[j] = 0.f; ss[j] = 0.f; }
     const size_t base = (size_t)g * P * C + c;
+    if (shift) VT<T>::load(x + base, kv);                                // pivot of the shifted sums: the group's first pixel
+    else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) kv[j] = 0.f;
+    }
     for (int64_t pp = p0 + tr; pp < p1; pp += (int64_t)rows * PIX) {
         float xv[PIX][VEC];
 #pragma unroll
@@ -373,22 +381,22 @@ __global__ __launch_bounds__(NTHR) void stats_stage1_vec(const T* __restrict__ x
             if (p < p1) VT<T>::load(x + base + (size_t)p * C, xv[k]);
             else {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) xv[k][j] = 0.f;
+                for (int j = 0; j < VEC; ++j) xv[k][j] = kv[j];           // contributes (k - k) = 0
             }
         }
 #pragma unroll
         for (int k = 0; k < PIX; ++k)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) { const double t = (double)xv[k][j]; s[j] += t; ss[j] = fma(t, t, ss[j]); }
+            for (int j = 0; j < VEC; ++j) { const float t = xv[k][j] - kv[j]; s[j] += t; ss[j] += t * t; }
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { red[threadIdx.x * 2 * VEC + j] = s[j]; red[threadIdx.x * 2 * VEC + VEC + j] = ss[j]; }
     __syncthreads();
     if (tr == 0) {
-        double* dst = partial + ((size_t)g * nchunks + ck) * 2 * C;
+        float* dst = partial + ((size_t)g * nchunks + ck) * 2 * C;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            double a = s[j], b = ss[j];
+            float a = s[j], b = ss[j];
             for (int rr = 1; rr < rows; ++rr) {                              // fixed order: deterministic
                 a += red[(threadIdx.x + rr * cv) * 2 * VEC + j];
                 b += red[(threadIdx.x + rr * cv) * 2 * VEC + VEC + j];
@@ -580,14 +588,14 @@ __global__ __launch_bounds__(NTHR) void norm_bwd_apply2_vec(const mg_norm_apply2
     }
 }
 
-// Stage 2 of the forward statistics: a block owns 16 channels; lanes 0..15 of each thread row sum the channels' partial sums, lanes
-// 16..31 their partial sums of squares (fp64, fixed order) and write sums[g][2][C] (fp64; x sum_scale: the statistics of a nearest 2x
-// upsample from its source, x 4, exact).  FIN: lanes 0..15 also run norm_finalize_kernel's arithmetic on those sums -- statistics that
-// need no cross-rank reduction in between (instance norm; batch norm on one GPU) finish in two launches, bit-identical to
-// mg_channel_stats + mg_norm_finalize.
-template <bool FIN>
-__global__ __launch_bounds__(256) void stats_stage2(const double* __restrict__ partial, double* __restrict__ sums,
-                                                    int nchunks, int C, double sum_scale, double count, float eps, float momentum,
+// Stage 2 of the forward statistics: a block owns 16 channels; lanes 0..15 of each thread row sum the channels' shifted partial sums,
+// lanes 16..31 their shifted partial sums of squares (fp64, fixed order), then lanes 0..15 un-shift with the pivot x[g][0][c] (0 without `shift`) in fp64
+// and write sums[g][2][C] (fp64; x sum_scale: the statistics of a nearest 2x upsample from its source, x 4, exact).
+// FIN: the same lanes also run norm_finalize_kernel's arithmetic on those fp64 sums -- statistics that need no cross-rank reduction in
+// between (instance norm; batch norm on one GPU) finish in two launches, bit-identical to mg_channel_stats + mg_norm_finalize.
+template <typename T, bool FIN>
+__global__ __launch_bounds__(256) void stats_stage2(const float* __restrict__ partial, const T* __restrict__ x, int64_t P, double* __restrict__ sums,
+                                                    int nchunks, int C, int shift, double sum_scale, double count, float eps, float momentum,
                                                     float* __restrict__ running_mean, float* __restrict__ running_var,
                                                     float* __restrict__ mean, float* __restrict__ rstd)
 {
@@ -600,57 +608,63 @@ __global__ __launch_bounds__(256) void stats_stage2(const double* __restrict__ p
     const int i = (cl >> 4) * C + c;                            // column of the [sum | sum of squares] vector
     double a = 0.0;
     if (c < C) {
-        const double* p = partial + (size_t)g * nchunks * C2 + i;
+        const float* p = partial + (size_t)g * nchunks * C2 + i;
         // eight independent loads in flight per thread (the trip count is a runtime value: without the explicit batch the loop was a
         // chain of ~64 dependent L2 round trips)
         int k = kk;
         for (; k + 56 < nchunks; k += 64) {
-            double v[8];
+            float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = p[(size_t)(k + 8 * j) * C2];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a += v[j];
+            for (int j = 0; j < 8; ++j) a += (double)v[j];
         }
-        for (; k < nchunks; k += 8) a += p[(size_t)k * C2];
+        for (; k < nchunks; k += 8) a += (double)p[(size_t)k * C2];
     }
     red[threadIdx.x] = a;
     __syncthreads();
     if (kk == 0) {
 #pragma unroll
         for (int r = 1; r < 8; ++r) a += red[r * 32 + cl];
-        fin[cl] = a * sum_scale;
-        if (c < C) sums[(size_t)g * C2 + i] = a * sum_scale;
+        fin[cl] = a;
     }
     __syncthreads();
-    if (FIN && threadIdx.x < 16 && c < C) {
-        const double s = fin[threadIdx.x], ss = fin[16 + threadIdx.x];
-        const double m = s / count;
-        double var = ss / count - m * m;
-        if (var < 0.0) var = 0.0;
-        mean[(size_t)g * C + c] = (float)m;
-        rstd[(size_t)g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (running_mean) {
-            const double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    if (threadIdx.x < 16 && c < C) {
+        const double kv = shift ? (double)ET<T>::load1(x + (size_t)g * P * C + c) : 0.0;
+        const double sh = fin[threadIdx.x], ssh = fin[16 + threadIdx.x], n = (double)P;
+        const double s = (sh + n * kv) * sum_scale;
+        const double ss = (ssh + 2.0 * kv * sh + n * kv * kv) * sum_scale;
+        sums[(size_t)g * C2 + c] = s;
+        sums[(size_t)g * C2 + C + c] = ss;
+        if (FIN) {
+            const double m = s / count;
+            double var = ss / count - m * m;
+            if (var < 0.0) var = 0.0;
+            mean[(size_t)g * C + c] = (float)m;
+            rstd[(size_t)g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (running_mean) {
+                const double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
         }
     }
 }
 
-// forward statistics: stage 1 (fp64 partial sums) + stage 2 (fp64 sums [+ finalize])
+// forward statistics: stage 1 (shifted fp32 partial sums) + stage 2 (fp64 sums [+ finalize])
 template <typename T, bool FIN>
-int run_stats(const void* x, int G, int64_t P, int C, double* sums, void* partial, double sum_scale, double count, float eps, float momentum,
+int run_stats(const void* x, int G, int64_t P, int C, int shift, double* sums, void* partial, double sum_scale, double count, float eps, float momentum,
               float* running_mean, float* running_var, float* mean, float* rstd, hipStream_t st)
 {
     const StatGeom sg = stat_geom(G, P, C);
     dim3 grid(sg.nchunks, G);
     if (vec_geom_ok<T>(C))
-        hipLaunchKernelGGL((stats_stage1_vec<T, 4>), grid, dim3(NTHR), 0, st, (const T*)x, (double*)partial, P, C, sg.chunk);
+        hipLaunchKernelGGL((stats_stage1_vec<T, 4>), grid, dim3(NTHR), 0, st, (const T*)x, (float*)partial, P, C, sg.chunk, shift);
     else
         hipLaunchKernelGGL((reduce_stage1<T, 0, true>), grid, dim3(NTHR), 0, st, (const T*)x, (const T*)nullptr, (const T*)nullptr, (const T*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, (T*)nullptr, (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, 0, 0.f, 0, 0, 0);
+                           (const float*)nullptr, (const float*)nullptr, (T*)nullptr, (float*)partial, P, C, sg.tpr, sg.rpb, sg.chunk, 0, 0.f, shift, 0, 0);
     MG_CHECK_LAUNCH("channel statistics (stage 1)");
-    hipLaunchKernelGGL((stats_stage2<FIN>), dim3((C + 15) / 16, G), dim3(256), 0, st, (const double*)partial, sums, sg.nchunks, C,
+    hipLaunchKernelGGL((stats_stage2<T, FIN>), dim3((C + 15) / 16, G), dim3(256), 0, st, (const float*)partial, (const T*)x, P, sums, sg.nchunks, C, shift,
                        sum_scale, count, eps, momentum, running_mean, running_var, mean, rstd);
     MG_CHECK_LAUNCH("channel statistics (stage 2)");
     return MG_OK;
@@ -700,18 +714,18 @@ extern "C" int64_t mg_stats_workspace(int32_t G, int64_t P, int32_t C)
 {
     if (G <= 0 || P <= 0 || C <= 0) return 0;
     const StatGeom sg = stat_geom(G, P, C);
-    return (int64_t)G * sg.nchunks * 2 * C * (int64_t)sizeof(double);      // forward statistics keep fp64 partial sums (the norm backward uses half of it)
+    return (int64_t)G * sg.nchunks * 2 * C * (int64_t)sizeof(float);
 }
 
-extern "C" int mg_channel_stats(const void* x, int32_t dtype, int32_t G, int64_t P, int32_t C,
+extern "C" int mg_channel_stats(const void* x, int32_t dtype, int32_t G, int64_t P, int32_t C, int32_t shift,
                                 double* sums, void* partial, void* stream)
 {
     MG_CHECK_NORM_GEOM("mg_channel_stats");
     MG_CHECK_ARG(x && sums && partial, "mg_channel_stats: null pointer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MG_BF16)
-        return run_stats<uint16_t, false>(x, G, P, C, sums, partial, 1.0, 1.0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, st);
-    return run_stats<float, false>(x, G, P, C, sums, partial, 1.0, 1.0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, st);
+        return run_stats<uint16_t, false>(x, G, P, C, shift != 0, sums, partial, 1.0, 1.0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, st);
+    return run_stats<float, false>(x, G, P, C, shift != 0, sums, partial, 1.0, 1.0, 0.f, 0.f, nullptr, nullptr, nullptr, nullptr, st);
 }
 
 extern "C" int mg_channel_stats_finalize(const void* x, int32_t dtype, int32_t G, int64_t P, int32_t C, float sum_scale, double count,
@@ -725,8 +739,8 @@ extern "C" int mg_channel_stats_finalize(const void* x, int32_t dtype, int32_t G
                  "mg_channel_stats_finalize: running statistics need both buffers and G == 1");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == MG_BF16)
-        return run_stats<uint16_t, true>(x, G, P, C, sums, partial, (double)sum_scale, count, eps, momentum, running_mean, running_var, mean, rstd, st);
-    return run_stats<float, true>(x, G, P, C, sums, partial, (double)sum_scale, count, eps, momentum, running_mean, running_var, mean, rstd, st);
+        return run_stats<uint16_t, true>(x, G, P, C, 1, sums, partial, (double)sum_scale, count, eps, momentum, running_mean, running_var, mean, rstd, st);
+    return run_stats<float, true>(x, G, P, C, 1, sums, partial, (double)sum_scale, count, eps, momentum, running_mean, running_var, mean, rstd, st);
 }
 
 extern "C" int mg_norm_act_fwd(const void* x, void* y, int32_t dtype, int32_t G, int64_t P, int32_t C,

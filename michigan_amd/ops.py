@@ -491,15 +491,16 @@ def _wgrad_launch(x, dy, taps, stride, want_bias, out=None):
     return (dw, dbias) if want_bias else dw
 
 
-def channel_sums(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
-    """x viewed as [G, P, C] -> fp64 [G, 2, C] (sum, sum of squares); deterministic two-stage reduce (shifted fp32 partial sums,
-    fp64 across chunks: mg_norm.hip)."""
+def channel_sums(x: torch.Tensor, groups: int = 1, shift: bool = False) -> torch.Tensor:
+    """x viewed as [G, P, C] -> fp64 [G, 2, C] (sum, sum of squares); deterministic two-stage reduce (fp32 partial sums per chunk,
+    fp64 across chunks: mg_norm.hip).  `shift`: accumulate x - x[g, 0, c] and un-shift in fp64 -- for STATISTICS (the variance must
+    not cancel against mean^2 in fp32); off for gradient column sums, whose mean is ~0 (a sample pivot would only add error)."""
     c = x.shape[-1]
     p = x.numel() // (groups * c)
     be = C.backend()
     ws = torch.empty(max(int(be.mg_stats_workspace(groups, p, c)), 4), dtype=torch.uint8, device=x.device)
     sums = torch.empty((groups, 2, c), dtype=torch.float64, device=x.device)
-    be.mg_channel_stats(_p(x), _dt(x), groups, p, c, _p(sums), _p(ws), _stream(x))
+    be.mg_channel_stats(_p(x), _dt(x), groups, p, c, int(shift), _p(sums), _p(ws), _stream(x))
     return sums
 
 
@@ -679,7 +680,7 @@ def batch_stats_begin(x: torch.Tensor, up: bool = False):
             x, scale = src, 4.0
         if SYNC_BN_GROUP is None and FUSED_STATS_FINALIZE:
             return ("fused", x, scale), None, count, c          # no cross-rank reduction: statistics + finalize in one entry (batch_stats_finish)
-        sums = channel_sums(x)
+        sums = channel_sums(x, shift=True)
         if scale != 1.0:
             sums.mul_(scale)
         work = None
@@ -1073,7 +1074,7 @@ class _InstanceNormActFn(torch.autograd.Function):
         if FUSED_STATS_FINALIZE:
             mean, rstd, _ = stats_finalize(x, n, float(p), eps)
         else:
-            sums = channel_sums(x, groups=n)
+            sums = channel_sums(x, groups=n, shift=True)
             mean = torch.empty((n, c), dtype=torch.float32, device=x.device)
             rstd = torch.empty((n, c), dtype=torch.float32, device=x.device)
             C.backend().mg_norm_finalize(_p(sums), n, c, float(p), eps, 0.0, None, None, _p(mean), _p(rstd), _stream(x))

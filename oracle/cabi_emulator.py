@@ -152,7 +152,7 @@ class EmulatorBackend:
     def mg_stats_workspace(self, G, P, C):
         return 16
 
-    def mg_channel_stats(self, x, dtype, G, P, C, sums, partial, stream=None):
+    def mg_channel_stats(self, x, dtype, G, P, C, shift, sums, partial, stream=None):
         xv = _view(x, (G, P, C), _TD[dtype]).double()
         s = _view(sums, (G, 2, C), torch.float64)
         s[:, 0] = xv.sum(1)
@@ -161,7 +161,7 @@ class EmulatorBackend:
 
     def mg_channel_stats_finalize(self, x, dtype, G, P, C, sum_scale, count, eps, momentum, running_mean, running_var, sums, mean, rstd,
                                   partial, stream=None):
-        self.mg_channel_stats(x, dtype, G, P, C, sums, partial)
+        self.mg_channel_stats(x, dtype, G, P, C, 1, sums, partial)
         _view(sums, (G, 2, C), torch.float64).mul_(sum_scale)
         return self.mg_norm_finalize(sums, G, C, count, eps, momentum, running_mean, running_var, mean, rstd)
 

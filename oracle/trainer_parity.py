@@ -37,13 +37,15 @@ G_BUFFERS = ("up_3.norm_0.param_free_norm.running_mean", "up_3.norm_0.param_free
              "up_3.conv_0.weight_u", "head_0.conv_1.weight_v", "up_0.conv_s.weight_u")
 D_BUFFERS = ("discriminator_0.model1.0.0.weight_u", "discriminator_1.model3.0.0.weight_v")
 LOSS_KEYS = ("GAN", "GAN_Feat", "VGG", "ORIENT", "D_Fake", "D_real")
-# Tolerance for everything behind an optimiser step on the HIP fp32 kernels.  tools/noise_probe.py (profiles/r03_noise_probe.txt) runs
-# the protocol twice on MI355X with two kernel pipelines that differ ONLY in fp32 accumulation order: the two runs land 4.2e-2 apart in the
-# running statistics of the last block and 4.9e-3 apart in the iteration-1 losses (Adam with beta1 = 0 is a sign function at the first
-# step), each 1.2e-2 ... 3.0e-2 from the reference's CPU run -- with identical iteration-0 results (2e-5).  1e-2 was inside that spread
-# and passed or failed with the rounding of unrelated kernels; 6e-2 is the spread plus a margin.  The deterministic float64 emulator runs
-# of the CPU suite keep 1e-2.
-RTOL_LATER_HIP = 6e-2
+# Tolerance for everything behind an optimiser step on the HIP fp32 kernels.  tools/noise_probe.py runs the protocol twice on MI355X
+# with two kernel pipelines that differ ONLY in fp32 accumulation order (LDS-DMA vs register-staged conv loaders), identical at
+# iteration 0 (3e-5).  Spread between the two runs / worst distance to the reference's CPU run:
+#   round 3 (profiles/r03_noise_probe.txt): running statistics 4.2e-2 / 3.0e-2, iteration-1 losses 4.9e-3 / 1.2e-2;
+#   round 4 (profiles/r04_noise_probe.txt, fp64 statistics sums): running statistics 2.7e-2 / 2.6e-2, iteration-1 losses 1.5e-2 / 1.5e-2.
+# (Adam with beta1 = 0 is a sign function at the first step: which weights flip is rounding luck.)  1e-2 sat inside that spread and
+# passed or failed with the rounding of unrelated kernels; 5e-2 = the largest spread seen between two correct runs + 20 %.  The
+# deterministic float64 emulator runs of the CPU suite keep 1e-2.
+RTOL_LATER_HIP = 5e-2
 
 
 def reference_argv(cfg, checkpoints_dir: str):

@@ -58,7 +58,7 @@ def test_argument_validation_without_gpu(lib_path):
     with pytest.raises(RuntimeError, match="null tensor pointer"):
         be.mg_conv_wgrad(w, None)
     with pytest.raises(RuntimeError, match="bad geometry"):
-        be.mg_channel_stats(64, _cabi.MG_F32, 1, 100, 6, 64, 64, None)
+        be.mg_channel_stats(64, _cabi.MG_F32, 1, 100, 6, 1, 64, 64, None)
 
 
 def test_kernels_are_gfx950_code_objects(lib_path):

@@ -247,10 +247,11 @@ def test_channel_stats_wide_and_grouped(dt):
     for shape, groups in (((1, 37, 29, 2048), 1), ((3, 33, 17, 128), 3), ((2, 129, 129, 64), 2), ((8, 8, 8, 1024), 1)):
         x = (torch.randn(shape, generator=g) + 0.5).to(DT[dt])
 
-        def fn(x):
-            return (ops.channel_sums(x, groups),)
-        (hip, _), (ref, _) = _both(fn, (x,))
-        _close(f"stats {shape} g={groups} {dt}", hip[0], ref[0], 1e-5)
+        for shift in (False, True):
+            def fn(x):
+                return (ops.channel_sums(x, groups, shift),)
+            (hip, _), (ref, _) = _both(fn, (x,))
+            _close(f"stats {shape} g={groups} {dt} shift={shift}", hip[0], ref[0], 1e-5)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
@@ -1145,7 +1146,7 @@ def test_batch_stats_keep_the_variance_under_a_large_mean(hip_backend, dt):
         if groups == 1:
             unb = var[0] * count / (count - 1)
             assert ((rv.double() - (0.9 + 0.1 * unb)) / (0.9 + 0.1 * unb)).abs().max().item() < 2e-6
-            mean_b, rstd_b, _, sums_b = ops.batch_stats_finish((ops.channel_sums(x), None, count, c), 1e-5, 0.0)
+            mean_b, rstd_b, _, sums_b = ops.batch_stats_finish((ops.channel_sums(x, shift=True), None, count, c), 1e-5, 0.0)
             assert ((rstd_b.double() - rstd_ref[0]) / rstd_ref[0]).abs().max().item() < 2e-6
             assert torch.equal(sums_b.reshape(-1), sums_a.reshape(-1))
 
@@ -1163,7 +1164,7 @@ def test_stats_finalize_fused_is_bit_identical_to_the_three_launch_path(hip_back
         rm0, rv0 = torch.randn(c, generator=g).cuda(), torch.rand(c, generator=g).cuda() + 0.5
         rm_a, rv_a = (rm0.clone(), rv0.clone()) if groups == 1 else (None, None)
         mean_a, rstd_a, sums_a = ops.stats_finalize(x, groups, count, 1e-5, 0.1, rm_a, rv_a, scale)
-        sums_b = ops.channel_sums(x, groups=groups)
+        sums_b = ops.channel_sums(x, groups=groups, shift=True)
         if scale != 1.0:
             sums_b.mul_(scale)
         mean_b = torch.empty((groups, c), device="cuda"); rstd_b = torch.empty((groups, c), device="cuda")

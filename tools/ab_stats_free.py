@@ -1,7 +1,10 @@
 """Upper bound of what 'batch / instance statistics in the producing convolution's epilogue'  could
 buy: the training step with EVERY statistics launch removed at zero cost -- ops.stats_finalize returns the (stale, same-shape) result of an
-earlier step instead of launching its two kernels -- against the normal step, A B A B in one process on the GPU box.  The numerics of the
-'free' arm are one step stale (sane values, not a training run); only its time means anything.      python tools/ab_stats_free.py"""
+earlier step instead of launching its two kernels -- against the normal step, A B A B in one process on the GPU box.  Both optimisers run
+with lr = 0 and the batch is fixed, so the cached statistics ARE the current ones (up to the spectral-norm power iteration's drift) and
+every arm computes on the same values: a first version let the stale statistics train the weights into a degenerate network, whose
+all-alike operands made every arm 6 % faster (the part clocks to its power budget: DESIGN 3.1) -- only time differences between arms
+of one repetition mean anything.      python tools/ab_stats_free.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import michigan_amd  # noqa: F401
@@ -13,6 +16,8 @@ from michigan_amd.synth import synth_batch
 opt = default_options(crop_size=512, gpu_ids=[0], compute_dtype="bf16")
 tr = Pix2PixTrainer(opt)
 data = {k: v.cuda() for k, v in synth_batch(8, 512, seed=1234).items()}
+for o in (tr.optimizer_G, tr.optimizer_D):
+    o.param_groups[0]["lr"] = 0.0
 
 
 def step():

@@ -35,7 +35,7 @@ p = n * h * w
 ws = torch.empty(max(int(be.mg_stats_workspace(1, p, c)), 4), dtype=torch.uint8, device="cuda")
 sums = torch.empty(1, 2, c, device="cuda")
 sums64 = torch.empty(1, 2, c, device="cuda", dtype=torch.float64)
-row("channel stats (BN sum, sum^2)  [8,512,512,128] bf16", T, timeit(lambda: be.mg_channel_stats(P(x), 1, 1, p, c, P(sums64), P(ws), st)))
+row("channel stats (BN sum, sum^2)  [8,512,512,128] bf16", T, timeit(lambda: be.mg_channel_stats(P(x), 1, 1, p, c, 1, P(sums64), P(ws), st)))
 dgb = torch.empty(n, h, w, 2 * c, device="cuda", dtype=bf)
 row("SPADE bwd reduce (4 reads, d[gamma|beta] write)", 6 * T, timeit(lambda: be.mg_norm_bwd_reduce(P(dh), P(hh), P(x), P(g1), 1, 1, p, c, P(mean), P(rstd), 2, 0.2, P(dgb), P(sums), P(ws), st)))
 dx = torch.empty_like(x); s1 = torch.zeros(c, device="cuda"); s2 = torch.zeros(c, device="cuda")
