@@ -1121,8 +1121,8 @@ def test_glue_kernels_match_contract(dt):
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_batch_stats_keep_the_variance_under_a_large_mean(hip_backend, dt):
     """VERDICT r3 (parity before speed): var = E[x^2] - E[x]^2 on fp32 sums loses mean^2 / var x 6e-8 of the variance.  The
-    reduction now accumulates in fp64 from the first add (per thread), keeps fp64 partial sums and fp64 sums up to finalize
-    (sync_batchnorm/batchnorm.py:128-145 computes the same one-pass formula on fp32 sums; batchnorm_reimpl.py:18-74 is the
+    reduction now accumulates x - x[g, 0, c] (pivot-shifted fp32 partial sums per chunk), adds and un-shifts them in fp64 and keeps fp64
+    sums up to finalize (sync_batchnorm/batchnorm.py:128-145 computes the same one-pass formula on fp32 sums; batchnorm_reimpl.py:18-74 is the
     two-pass yardstick).  mean^2 / var = 1.4e6 in fp32 (the old path: ~9 % error on rstd^-2), 4e3 on bf16-representable values;
     both paths (fused finalize, stats + all-reduce-able fp64 sums + finalize) against float64 on the same values: 2e-6."""
     from michigan_amd import ops
