@@ -18,7 +18,7 @@ NAMES = {
     "bench_rccl1_two_groups.json": "r04_bench_rccl1_two_groups.json", "bench_deterministic.json": "r04_bench_deterministic.json",
     "bench_gloo2.json": "r04_bench_gloo_2ranks_one_gpu.json", "conv_census.txt": "r04_conv_census.txt", "pmc_halo.txt": "r04_pmc_halo.txt",
     "noise_probe.txt": "r04_noise_probe.txt", "grad_probe.txt": "r04_grad_probe.txt", "ab_stats_free.txt": "r04_ab_stats_free_rerun.txt",
-    "inpaint_err_probe.txt": "r04_inpaint_err_probe_rerun.txt", "pytest_gpu.log": "r04_pytest_gpu_tail.txt", "rc.log": "r04_evidence_rc.txt",
+    "inpaint_err_probe.txt": "r04_inpaint_err_probe_rerun.txt", "mfma_ceiling.txt": "r04_mfma_ceiling_rerun.txt", "pytest_gpu.log": "r04_pytest_gpu_tail.txt", "rc.log": "r04_evidence_rc.txt",
 }
 NOISE = ("amdgpu.ids", "Network [")
 

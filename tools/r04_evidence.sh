@@ -2,7 +2,7 @@
 # Round-4 evidence in one GPU-box call (through gpurun from the repo root):  bash tools/r04_evidence.sh
 #   full GPU suite + smoke + the default bench line (tools/r04_check.sh), bs 4, the in-painting branch, one-rank RCCL with every collective
 #   forced (one communicator = default / MG_DP_TWO_GROUPS=1), MG_DETERMINISTIC=1, 2-rank gloo self-spawn smoke, conv census, MFMA counters of
-#   the halo conv, the trainer noise probe, the statistics-free upper bound, the fp32 gradient probe.
+#   the halo conv, the trainer noise probe, the statistics-free upper bound, the fp32 gradient probe, the MFMA + LDS-feed ceiling probe.
 set -u
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r04; mkdir -p $OUT; cd $R
 bash tools/r04_check.sh r04 > $OUT/check.log 2>&1; tail -12 $OUT/check.log | cut -c1-400
@@ -17,6 +17,7 @@ timeout 300 python tools/conv_census.py > $OUT/conv_census.txt 2> $OUT/conv_cens
 timeout 300 python tools/ab_stats_free.py > $OUT/ab_stats_free.txt 2>&1; echo "ab_stats_free rc=$?" | tee -a $OUT/rc.log
 timeout 400 python tools/noise_probe.py > $OUT/noise_probe.txt 2>&1; echo "noise_probe rc=$?" | tee -a $OUT/rc.log
 timeout 500 python tools/grad_probe.py > $OUT/grad_probe.txt 2>&1; echo "grad_probe rc=$?" | tee -a $OUT/rc.log
+(hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_ceiling tools/mfma_ceiling.hip 2>/dev/null && timeout 120 /tmp/mfma_ceiling) > $OUT/mfma_ceiling.txt 2>&1; echo "mfma_ceiling rc=$?" | tee -a $OUT/rc.log
 timeout 600 bash tools/pmc_conv.sh > $OUT/pmc_halo.txt 2>&1; echo "pmc_conv rc=$?" | tee -a $OUT/rc.log; rm -rf gpurun_out/pmc
 for f in bench_again bench_bs4 bench_inpaint bench_rccl1_one_group bench_rccl1_two_groups bench_deterministic bench_gloo2; do echo "$f: $(cut -c1-170 $OUT/$f.json)"; done
 grep -v "^Network\|amdgpu" $OUT/ab_stats_free.txt | tail -9; tail -12 $OUT/noise_probe.txt | cut -c1-250; cat $OUT/rc.log
