@@ -4,8 +4,8 @@
 #   forced (one communicator = default / MG_DP_TWO_GROUPS=1), MG_DETERMINISTIC=1, 2-rank gloo self-spawn smoke, conv census, MFMA counters of
 #   the halo conv, the trainer noise probe, the statistics-free upper bound, the fp32 gradient probe, the MFMA + LDS-feed ceiling probe.
 set -u
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r04; mkdir -p $OUT; cd $R
-bash tools/r04_check.sh r04 > $OUT/check.log 2>&1; tail -12 $OUT/check.log | cut -c1-400
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/${1:-r04}; mkdir -p $OUT; cd $R
+bash tools/r04_check.sh ${1:-r04} > $OUT/check.log 2>&1; tail -12 $OUT/check.log | cut -c1-400
 timeout 300 python bench.py --batch-per-gpu 4 --no-cpu-baseline --no-traffic --no-extra > $OUT/bench_bs4.json 2> $OUT/bench_bs4.err; echo "bench_bs4 rc=$?" | tee -a $OUT/rc.log
 timeout 300 python bench.py --inpaint-orient --no-cpu-baseline --no-traffic --no-extra > $OUT/bench_inpaint.json 2> $OUT/bench_inpaint.err; echo "inpaint rc=$?" | tee -a $OUT/rc.log
 timeout 300 python bench.py --no-cpu-baseline --no-traffic --no-extra > $OUT/bench_again.json 2> $OUT/bench_again.err; echo "bench_again rc=$?" | tee -a $OUT/rc.log
