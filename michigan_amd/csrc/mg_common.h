@@ -6,6 +6,10 @@
 #include <stdarg.h>
 #include "michigan_hip.h"
 
+#ifndef MG_F32_ONE_CHAIN
+#define MG_F32_ONE_CHAIN 0   // 1: fp32 MFMA sums as ONE sequential chain per output (rounds 1-3) instead of two-level sums: A/B builds only
+#endif
+
 typedef __attribute__((ext_vector_type(8)))  __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4)))  short  s16x4_t;
 typedef __attribute__((ext_vector_type(4)))  float  f32x4_t;

@@ -13,7 +13,7 @@
 // double-buffered with one barrier per K chunk; the next chunk's global loads
 // are issued before the current chunk's MFMAs (latency hides under the matrix
 // pipe).  bf16 uses v_mfma_f32_32x32x16_bf16, f32 uses v_mfma_f32_32x32x2_f32
-// (exact fp32 fma chain) -- same tiling, same LDS image (64 B of K per row).
+// (exact fp32 fma; two-level sums, mma_f32_chunk) -- same tiling, same LDS image (64 B of K per row).
 
 int g_mg_conv_splitk_wide = 0;   // ... also for launches of 161..320 workgroups with >= 256 K steps (mg_set_option(17, 1)): measured flat, off
 int g_mg_conv_splitk = 1;        // deterministic split-K for low-resolution long-K layers (mg_set_option(5, v))

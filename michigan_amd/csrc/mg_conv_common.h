@@ -43,6 +43,58 @@ namespace {
 // (SQ_LDS_BANK_CONFLICT = 1/3 of SQ_LDS_IDX_ACTIVE, profiles/r01_pmc_conv.txt).
 __device__ __forceinline__ int lds_off(int row, int piece) { return row * ROWB + ((piece ^ ((row >> 2) & 3)) << 4); }
 
+
+// fp32: the 16 K values of one 64-byte chunk, for every 32x32 tile of a wave, as TWO-LEVEL sums.  v_mfma_f32_32x32x2_f32 adds two K terms
+// to its accumulator per issue; chaining every issue of a layer into the same accumulator makes each output ONE sequential fp32 chain of
+// K = taps x Cin terms (1152 ... 9216 on the hot path), whose rounding error grows like sqrt(K): 4.4e-7 ... 1.2e-6 relative against
+// 1.3e-7 ... 3.1e-7 for a CPU kernel that keeps 16 lanes of partial sums (tools/fp32_chain_error.py) -- and every (Leaky)ReLU whose
+// pre-activation changes sign under that error moves a gradient by its full magnitude (tools/grad_probe.py).  Here the
+// chunk's 8 issues start from ZERO in a temporary tile and the finished 16-term block sum is added to the layer accumulator once:
+// blocks of 16, then a chain of K / 16 block sums -- 1.7e-7 ... 4.4e-7, a CPU kernel's error to within 1.4x.  GT = 2 temporaries in flight keep
+// dependent issues GT MFMAs apart; 16 v_add_f32 per tile and chunk ride in the shadow of 8 x 64 MFMA cycles.
+template <int MT, int NT>
+__device__ __forceinline__ void mma_f32_chunk(const f32x4_t (&a)[MT][2], const f32x4_t (&b)[NT][2], f32x16_t (&acc)[MT][NT])
+{
+#if MG_F32_ONE_CHAIN                                              // A/B build (tools/build_variant.py ... -DMG_F32_ONE_CHAIN=1): the single chain of rounds 1-3
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j >> 2][j & 3], b[nt][j >> 2][j & 3], acc[mt][nt], 0, 0, 0);
+    return;
+#endif
+    constexpr int TILES = MT * NT, GT = TILES >= 2 ? 2 : TILES;
+    static_assert(TILES % GT == 0, "tile groups");
+#pragma unroll
+    for (int g0 = 0; g0 < TILES; g0 += GT) {
+        f32x16_t t[GT];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int g = 0; g < GT; ++g) {
+                const int mt = (g0 + g) / NT, nt = (g0 + g) % NT;
+                f32x16_t c;
+                if (j == 0) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) c[e] = 0.f;
+                } else {
+                    c = t[g];
+                }
+                t[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j >> 2][j & 3], b[nt][j >> 2][j & 3], c, 0, 0, 0);
+            }
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+            const int mt = (g0 + g) / NT, nt = (g0 + g) % NT;
+            acc[mt][nt] += t[g];
+            // pin the add HERE: nothing needs the layer accumulator before the epilogue, so the compiler otherwise sinks every chunk's
+            // adds down there and keeps all the block sums alive until then (9 taps x 64 registers of them: 750 spills)
+            asm volatile("" : "+v"(acc[mt][nt]));
+        }
+    }
+}
+
 template <typename T, int MT, int NT>
 __device__ __forceinline__ void conv_compute(const unsigned char* As, const unsigned char* Bs, int l31, int hi,
                                              f32x16_t (&acc)[MT][NT])
@@ -81,14 +133,7 @@ __device__ __forceinline__ void conv_compute(const unsigned char* As, const unsi
             b[nt][0] = *reinterpret_cast<const f32x4_t*>(Bs + (nt * 32 + l31) * ROWB + p0);
             b[nt][1] = *reinterpret_cast<const f32x4_t*>(Bs + (nt * 32 + l31) * ROWB + p1);
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j >> 2][j & 3], b[nt][j >> 2][j & 3],
-                                                                       acc[mt][nt], 0, 0, 0);
+        mma_f32_chunk<MT, NT>(a, b, acc);
     }
 }
 

@@ -73,7 +73,7 @@ __device__ __forceinline__ unsigned long long stamp()
 }
 
 template <typename T, int EPI, int WM, int NT, int PROBE = 0>
-__global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(const ConvK d)
+__global__ __launch_bounds__(NTHR, (NT == 4 || sizeof(T) == 4 ? 2 : 3)) void conv3x3_halo_kernel(const ConvK d)
 {
     using G = HaloGeom<WM, NT>;
     constexpr int PF = RING - 1;                               // weight slabs in flight ahead of the tap being computed
@@ -240,14 +240,7 @@ __global__ __launch_bounds__(NTHR, (NT == 4 ? 2 : 3)) void conv3x3_halo_kernel(c
                 b[nt][0] = *reinterpret_cast<const f32x4_t*>(smem + boff[t][nt]);
                 b[nt][1] = *reinterpret_cast<const f32x4_t*>(smem + (boff[t][nt] ^ KX));
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j >> 2][j & 3], b[nt][j >> 2][j & 3],
-                                                                           acc[mt][nt], 0, 0, 0);
+            mma_f32_chunk<MT, NT>(a, b, acc);              // two-level sums: mg_conv_common.h
         }
     };
 
@@ -416,6 +409,10 @@ template <typename T, int EPI>
 int launch_halo(ConvK& k, hipStream_t st)
 {
     if (k.Cout_gemm <= 64) return launch_halo_g<T, EPI, 1, 2>(k, st);
+    // fp32 (the parity configuration): always the 64-accumulator geometry -- the two-level sums of mma_f32_chunk keep 64 more registers
+    // of temporaries in flight, which the 128-accumulator tile has no room for at two workgroups per CU
+    if constexpr (sizeof(T) == 4) return launch_halo_g<T, EPI, 2, 2>(k, st);
+    else {
     // 16x16-pixel tiles once they still give every CU its two workgroups at least twice over
     const long big = (long)k.N * ((k.Hin + 15) / 16) * ((k.Win + 15) / 16) * ((k.Cout_gemm + 127) / 128);
     if (g_mg_conv_halo_big && k.Hin >= 16 && big >= 1024) {
@@ -432,6 +429,7 @@ int launch_halo(ConvK& k, hipStream_t st)
         return launch_halo_g<T, EPI, 2, 4>(k, st);
     }
     return launch_halo_g<T, EPI, 2, 2>(k, st);
+    }
 }
 
 }  // namespace

@@ -193,21 +193,44 @@ __global__ __launch_bounds__(NTHR) void wgrad_kernel(const WgK d)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
             }
         } else {
+            // two-level sums (mg_conv_common.h, mma_f32_chunk): a panel's KP pixel terms start from zero in a temporary tile and the block sum
+            // is added to the split's accumulator once -- the split's sum over up to 10^5 pixels is otherwise ONE sequential fp32 chain
+            f32x16_t t[2][2];
 #pragma unroll
             for (int kk = 0; kk < KP / 2; ++kk) {
                 float a[2], b[2];
                 const int row = kk * 2 + hi;
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    a[t] = *reinterpret_cast<const float*>(As + row * RS + (wm * 64 + t * 32 + l31) * 4);
-                    b[t] = *reinterpret_cast<const float*>(Bs + row * RS + (wn * 64 + t * 32 + l31) * 4);
+                for (int q = 0; q < 2; ++q) {
+                    a[q] = *reinterpret_cast<const float*>(As + row * RS + (wm * 64 + q * 32 + l31) * 4);
+                    b[q] = *reinterpret_cast<const float*>(Bs + row * RS + (wn * 64 + q * 32 + l31) * 4);
                 }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < 2; ++nt) {
+                        f32x16_t c;
+                        if (MG_F32_ONE_CHAIN) {
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                            continue;
+                        }
+                        if (kk == 0) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) c[e] = 0.f;
+                        } else {
+                            c = t[mt][nt];
+                        }
+                        t[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], c, 0, 0, 0);
+                    }
             }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    if (MG_F32_ONE_CHAIN) continue;
+                    acc[mt][nt] += t[mt][nt];
+                    asm volatile("" : "+v"(acc[mt][nt]));            // keep the add here (see mma_f32_chunk)
+                }
         }
     };
 

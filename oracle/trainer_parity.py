@@ -37,15 +37,15 @@ G_BUFFERS = ("up_3.norm_0.param_free_norm.running_mean", "up_3.norm_0.param_free
              "up_3.conv_0.weight_u", "head_0.conv_1.weight_v", "up_0.conv_s.weight_u")
 D_BUFFERS = ("discriminator_0.model1.0.0.weight_u", "discriminator_1.model3.0.0.weight_v")
 LOSS_KEYS = ("GAN", "GAN_Feat", "VGG", "ORIENT", "D_Fake", "D_real")
-# Tolerance for everything behind an optimiser step on the HIP fp32 kernels.  tools/noise_probe.py runs the protocol twice on MI355X
-# with two kernel pipelines that differ ONLY in fp32 accumulation order (LDS-DMA vs register-staged conv loaders), identical at
-# iteration 0 (3e-5).  Spread between the two runs / worst distance to the reference's CPU run:
-#   round 3 (profiles/r03_noise_probe.txt): running statistics 4.2e-2 / 3.0e-2, iteration-1 losses 4.9e-3 / 1.2e-2;
-#   round 4 (profiles/r04_noise_probe.txt, fp64 statistics sums): running statistics 2.7e-2 / 2.6e-2, iteration-1 losses 1.5e-2 / 1.5e-2.
-# (Adam with beta1 = 0 is a sign function at the first step: which weights flip is rounding luck.)  1e-2 sat inside that spread and
-# passed or failed with the rounding of unrelated kernels; 5e-2 = the largest spread seen between two correct runs + 20 %.  The
-# deterministic float64 emulator runs of the CPU suite keep 1e-2.
-RTOL_LATER_HIP = 5e-2
+# Tolerance for everything behind an optimiser step on the HIP fp32 kernels (Adam with beta1 = 0 is a sign function at the first step:
+# which near-zero gradients flip is rounding luck in ANY fp32 implementation, the reference's own CPU run included).
+# tools/noise_probe.py runs the protocol on MI355X with the two conv pipelines and reports the distance to the reference's CPU run:
+#   rounds 3 / 4 with ONE fp32 accumulation chain per output (profiles/r03_noise_probe.txt, r04_noise_probe_one_chain.txt): running
+#     statistics 2.6e-2 ... 3.0e-2, iteration-1 losses 1.2e-2 ... 1.5e-2, and the two pipelines 2.7e-2 ... 4.2e-2 apart from each other;
+#   round 4 with two-level fp32 sums (profiles/r04_noise_probe.txt; forward error below ATen's): fixture A running statistics 8.6e-3,
+#     iteration-1 losses 1.1e-3; fixture B running statistics 1.5e-2, it0.loss.D_Fake 1.4e-3 (tools/dfake_probe.py).
+# 3e-2 = twice the largest distance seen with the shipped kernels.  The deterministic float64 emulator runs of the CPU suite keep 1e-2.
+RTOL_LATER_HIP = 3e-2
 
 
 def reference_argv(cfg, checkpoints_dir: str):
@@ -120,12 +120,16 @@ def compare(rec, gold, *, rtol_loss0, rtol_later, atol_img, atol_weight):
     145) makes its first update lr * g / |g| -- a sign function -- so a gradient that differs in its last bits around zero
     moves that weight by 2 * lr in the other direction; such weights shift iteration-1 losses and the running statistics in
     ANY two correct implementations (the reference on two BLAS builds included) -- measured on MI355X between two fp32
-    kernel pipelines: up to 5e-3 on the losses and 4e-2 on the running statistics (RTOL_LATER_HIP above).
+    kernel pipelines and against the reference's CPU run (RTOL_LATER_HIP above).
     Weights themselves: at most 1 % of a tensor's elements may be further than `atol_weight` (stated in units of lr)."""
     bad = []
     for k in gold.files:
         want, got = gold[k], rec[k]
-        first = k.startswith("it0.")
+        # iteration 0 = everything computed BEFORE the first optimiser step.  it0.loss.D_Fake is not: the discriminator step scores the image
+        # of the generator AFTER its first Adam step (pix2pix_trainer.py:39-77) -- on fixture B the reference's own fp32 run, the float64
+        # emulator and two HIP accumulation orders land 1e-4 ... 1.4e-3 apart there while every other iteration-0 loss agrees to 2e-6
+        # (tools/dfake_probe.py, profiles/r04_dfake_probe.txt: the generator gradients of the same geometry are 2.5e-6 from float64)
+        first = k.startswith("it0.") and k != "it0.loss.D_Fake"
         if ".loss." in k:
             err, lim = abs(float(got) - float(want)), (rtol_loss0 if first else rtol_later) * max(abs(float(want)), 0.1)
         elif k.endswith("generated") or k.endswith("generated_stat"):

@@ -111,7 +111,7 @@ def test_generator_fullwidth_gradients_match_oracle_autograd(hip_backend):
     256x256, batch 2, on the HIP kernels and is compared with torch autograd through the oracle restatement on the
     host for parameters of every kind the wide layers have (spectral-normed 3x3 at 1024 and 512 channels, a 1x1
     shortcut, gamma / beta convs, the partial-conv encoder's 1024-channel layer, a bias).
-    Tolerance: 1.5e-2 of each tensor's largest gradient element and 1.2e-2 relative L2 against the oracle run in float64 (see below)."""
+    Tolerance: 1e-2 of each tensor's largest gradient element and 5e-3 relative L2 against the oracle run in float64 (see below)."""
     from michigan_amd import networks
     from michigan_amd.model import default_options
     from michigan_amd.synth import synth_batch, synth_state_dict
@@ -143,16 +143,16 @@ def test_generator_fullwidth_gradients_match_oracle_autograd(hip_backend):
         return ref_out.detach(), {n: osd[n].grad.double() for n in names}
     # The fp64 run of the oracle is the yardstick; its own fp32 run (ATen) measures how well-conditioned each gradient is.  What separates two
     # CORRECT fp32 implementations here are activation sign flips: an element of a (Leaky)ReLU input within the forward rounding error of 0
-    # takes the other branch, which moves that element's gradient by 80 % -- tools/grad_probe.py, profiles/r04_grad_probe.txt: the error at
-    # the first block boundary behind the image is three such elements of 8.4 M, every parameter gradient is a sum over them, and the
-    # layers at the far end of the backward pass (fc.layer5, head_0: 4 x 4 latent) collect all of them.  How many flip is set by the forward
-    # error: 1e-6 ... 2.4e-6 relative per block for the HIP kernels against 0.5e-6 ... 1.2e-6 for ATen (the fp32 MFMA accumulates K = 1152 ...
-    # 9216 terms as ONE fma chain, oneDNN in 16 lanes: 4e-7 ... 1.2e-6 against 1.3e-7 ... 3.3e-7 per output).  Round 4 measured the same
-    # network under three statistics kernels (one-pass fp32 sums / pivot-shifted fp32 / fp64 accumulation, the shipped one): fc.layer5
-    # 1.0e-2 / 4.2e-3 / 1.0e-2, head_0.conv_0 9.2e-3 / 3.1e-3 / 9.8e-3 -- the spread is which elements flip, not the statistics (VERDICT r3
-    # suspected the one-pass variance; its conditioning is pinned separately in tests/test_gpu_kernels.py::test_batch_stats_keep_the_
-    # variance_under_a_large_mean).  Bounds per tensor: max-abs error <= 1.5e-2 of the largest element and relative L2 error <= 1.2e-2, or
-    # twice the ATen-fp32 distance where that is larger.
+    # takes the other branch, which moves that element's gradient by 80 % -- tools/grad_probe.py, profiles/r04_grad_probe*.txt: every
+    # parameter gradient is a sum over such elements, and the layers at the far end of the backward pass (fc.layer5, head_0: 4 x 4 latent)
+    # collect all of them.  How many flip is set by the forward error.  Rounds 1-3 chained every fp32 MFMA of a layer into one accumulator
+    # -- ONE sequential chain of K = 1152 ... 9216 terms per output, 1e-6 ... 2.9e-6 relative per block against 0.6e-6 ... 1.4e-6 for ATen --
+    # and sat at 1.4e-3 ... 1.0e-2 here (bounds 1.5e-2 / 1.2e-2).  Since round 4 the fp32 kernels form two-level sums (16-term blocks from
+    # zero, then the block sums: mma_f32_chunk, csrc/mg_conv_common.h; tools/fp32_chain_error.py): forward error 0.4e-6 ... 1.0e-6, BELOW
+    # ATen's, and on this test max-abs 6.5e-4 ... 2.5e-3, relative L2 8.6e-4 ... 1.5e-3 (ATen: 2.5e-4 ... 2.8e-2 / 3.0e-4 ... 1.7e-3).  Bounds per
+    # tensor, the ones VERDICT r3 asked to return to: max-abs error <= 1e-2 of the largest element and relative L2 error <= 5e-3, or twice
+    # the ATen-fp32 distance where that is larger.  (The batch statistics behind it -- VERDICT r3 suspected their one-pass variance -- are
+    # pinned separately: tests/test_gpu_kernels.py::test_batch_stats_keep_the_variance_under_a_large_mean.)
     out64, ref64 = oracle_grads(torch.float64)
     _, ref32 = oracle_grads(torch.float32)
     assert (out.detach().double().cpu() - out64).abs().max().item() < 1e-3
@@ -162,7 +162,7 @@ def test_generator_fullwidth_gradients_match_oracle_autograd(hip_backend):
     w2, c2 = {n: rl2(got[n], ref64[n]) for n in names}, {n: rl2(ref32[n], ref64[n]) for n in names}
     print("full-width gradient errors vs fp64 oracle, max-abs (HIP fp32 | ATen fp32):", {n: "%.1e | %.1e" % (worst[n], cond[n]) for n in names})
     print("full-width gradient errors vs fp64 oracle, relative L2 (HIP fp32 | ATen fp32):", {n: "%.1e | %.1e" % (w2[n], c2[n]) for n in names})
-    bad = {n: (worst[n], cond[n], w2[n], c2[n]) for n in names if worst[n] > max(1.5e-2, 2 * cond[n]) or w2[n] > max(1.2e-2, 2 * c2[n])}
+    bad = {n: (worst[n], cond[n], w2[n], c2[n]) for n in names if worst[n] > max(1e-2, 2 * cond[n]) or w2[n] > max(5e-3, 2 * c2[n])}
     assert not bad, bad
 
 

@@ -2,7 +2,7 @@
 contract emulator (oracle/cabi_emulator.py) on identical inputs.
 
 Tolerances (stated per dtype):
-  f32  : |hip - ref| <= 2e-5 * max|ref|   (fp32 MFMA = exact fma chain; only the
+  f32  : |hip - ref| <= 2e-5 * max|ref|   (fp32 MFMA = exact fma, two-level sums; only the
          summation order differs from the float64 emulator)
   bf16 : |hip - ref| <= 2^-7 * max|ref|   (one bf16 ulp at the top of the range:
          both sides round an fp32/fp64 accumulation to bf16 once)

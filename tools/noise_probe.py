@@ -1,8 +1,8 @@
 """How far apart do two CORRECT fp32 runs of the trainer-parity protocol land behind the optimiser steps?  (GPU box.)
-Runs fixture A (oracle/trainer_parity.py) twice on the HIP kernels -- LDS-DMA conv pipeline vs the register-staged one
+Runs fixture A (or B: argv[1]; oracle/trainer_parity.py) twice on the HIP kernels -- LDS-DMA conv pipeline vs the register-staged one
 (mg_set_option(0, .): same arithmetic, different accumulation order) -- for both trainer flows (this repo's FlatAdam trainer / the
 reference trainer's flow with torch.optim.Adam) and prints, per quantity class, the largest error against the reference goldens in
-units of the test tolerance, and the spread between the two runs.     python tools/noise_probe.py"""
+units of the test tolerance, and the spread between the two runs.     python tools/noise_probe.py [A|B]"""
 import os, sys
 import numpy as np
 import torch
@@ -12,8 +12,9 @@ from oracle import trainer_parity as TP
 from michigan_amd import _cabi
 from michigan_amd.model import Pix2PixModel, Pix2PixTrainer
 
-gold = np.load(os.path.join(ROOT, "tests", "golden", "trainer_A.npz"))
-cfg = TP.CFGS["A"]
+FIX = sys.argv[1] if len(sys.argv) > 1 else "A"              # fixture: A (two iterations) or B (one iteration with the in-painting net)
+gold = np.load(os.path.join(ROOT, "tests", "golden", "trainer_%s.npz" % FIX))
+cfg = TP.CFGS[FIX]
 
 
 def run(flow, pipeline):
@@ -38,6 +39,8 @@ def run(flow, pipeline):
 
 def classes(k):
     if ".loss." in k:
+        if k == "it0.loss.D_Fake":
+            return "loss it0 D_Fake"                          # computed on the image of the generator AFTER its first Adam step
         return ("loss it0" if k.startswith("it0.") else "loss it1")
     if "generated" in k:
         return "image"
@@ -69,6 +72,6 @@ for flow in ("repo", "reflike"):
         if max(e1, e2) > max(w[0], w[1]):
             w[0], w[1], w[3] = e1, e2, k
         w[2] = max(w[2], sp)
-    print("flow %s" % flow)
+    print("fixture %s, flow %s" % (FIX, flow))
     for c, (e1, e2, sp, k) in sorted(worst.items()):
         print("  %-14s vs golden: %.3e (LDS-DMA) %.3e (register-staged)   spread between the two runs: %.3e   [%s]" % (c, e1, e2, sp, k))
