@@ -411,7 +411,7 @@ int launch_halo(ConvK& k, hipStream_t st)
     if (k.Cout_gemm <= 64) return launch_halo_g<T, EPI, 1, 2>(k, st);
     // fp32 (the parity configuration): always the 64-accumulator geometry -- the two-level sums of mma_f32_chunk keep 64 more registers
     // of temporaries in flight, which the 128-accumulator tile has no room for at two workgroups per CU
-    if constexpr (sizeof(T) == 4) return launch_halo_g<T, EPI, 2, 2>(k, st);
+    if constexpr (sizeof(T) == 4) return launch_halo_g<T, EPI, 2, 2>(k, st);   // (128-accumulator tile + ONE temporary: 90 spills, 99.8 vs 104.8 images/s on configs[1])
     else {
     // 16x16-pixel tiles once they still give every CU its two workgroups at least twice over
     const long big = (long)k.N * ((k.Hin + 15) / 16) * ((k.Win + 15) / 16) * ((k.Cout_gemm + 127) / 128);
