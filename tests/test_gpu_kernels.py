@@ -119,6 +119,37 @@ def test_conv2d_fwd_bwd(case, dt):
         _close(f"conv {case} {dt} {name}", a, r, TOL[dt] * (4 if name in ("dw", "db") and dt == "bf16" else 1))
 
 
+def test_fp32_conv_sums_are_two_level(hip_backend):
+    """The fp32 kernels' accuracy property, pinned: every output of a K = 9216-term convolution (1024 channels x 3x3, the hot path's
+    longest reduction) is a two-level sum -- 16-term blocks from zero, then the block sums (csrc/mg_conv_common.h mma_f32_chunk, round
+    4) -- not ONE sequential fp32 chain.  tools/fp32_chain_error.py: rms error of such a dot product against float64 4.4e-7 two-level,
+    1.2e-6 as one chain (what rounds 1-3 did: 2x ATen's forward error, and with it the ReLU sign flips that dominated the fp32
+    gradient distance).  Forward (halo kernel), data gradient (same kernel, transposed weights) and weight gradient (pixels as K:
+    8 x 32 x 32 = 8192 terms per split-free sum) against float64 on the same fp32 values; bounds = 1.5x the two-level figure."""
+    from michigan_amd import ops
+    g = torch.Generator().manual_seed(77)
+    N, H, W, C = 8, 32, 32, 1024
+    x = torch.relu(torch.randn(N, H, W, C, generator=g)).requires_grad_()
+    w = (torch.randn(64, C, 3, 3, generator=g) / (9 * C) ** 0.5).requires_grad_()
+    gy = torch.randn(N, H, W, 64, generator=g)
+    xc, wc = x.detach().cuda().requires_grad_(), w.detach().cuda().requires_grad_()
+    y = ops.conv2d(xc, wc, None, stride=1, padding=1)
+    gx, gw = torch.autograd.grad(y, (xc, wc), gy.cuda())
+    torch.cuda.synchronize()
+    xd, wd = x.detach().double().permute(0, 3, 1, 2).requires_grad_(), w.detach().double().requires_grad_()
+    yd = torch.nn.functional.conv2d(xd, wd, None, stride=1, padding=1)
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), gy.double().permute(0, 3, 1, 2))
+    rms = lambda a, b: float(((a.double().cpu() - b).norm() / b.norm()))
+    e_y = rms(y.permute(0, 3, 1, 2), yd.detach())
+    e_dx = rms(gx.permute(0, 3, 1, 2), gxd)
+    e_dw = rms(gw, gwd)
+    print("fp32 two-level sums, rms relative error vs float64: y %.2e  dx %.2e  dw %.2e" % (e_y, e_dx, e_dw))
+    # measured on MI355X: y 4.2e-7, dx 1.3e-7, dw 1.4e-7; the -DMG_F32_ONE_CHAIN=1 build: 1.17e-6, 4.2e-7, 2.8e-7 (fails all three)
+    assert e_y < 6.6e-7, e_y            # K = 9216: the numpy model gives 4.4e-7 two-level, 1.2e-6 as one chain
+    assert e_dx < 2.5e-7, e_dx          # K = 576 (64 channels x 9 taps)
+    assert e_dw < 2.1e-7, e_dw          # K = 8192 pixels, shortened by the split-K
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv2d_residual_and_tanh(dt):
     from michigan_amd import ops
