@@ -17,7 +17,7 @@
 // Online softmax per query column: running max m (synchronised between the two half-waves that share a query), running
 // partial row sum l (added across the halves at the end), O rescaled only when some lane's max moved (wave-uniform branch).
 // bf16: v_mfma_f32_32x32x16_bf16, fp32 accumulation everywhere, P enters the second product as a hi + lo pair of bf16 values;
-// fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fma chains: the parity configuration).
+// fp32: v_mfma_f32_32x32x2_f32 (exact fp32 fma, two-level sums over the keys: the parity configuration).
 #include "mg_common.h"
 
 namespace {
@@ -227,13 +227,33 @@ __global__ __launch_bounds__(NTHR_A, 1) void self_attention_kernel(const AttnArg
                     }
                 }
         } else {
+            // two-level sums, like the fp32 convolutions (mg_conv_common.h mma_f32_chunk): the 32 keys of this tile are summed from zero in a
+            // temporary and added to the running output once -- chaining all L = 4096 keys into the accumulator is one sequential fp32 sum
+            // per output.  Two channel blocks in flight keep dependent issues two MFMAs apart.
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = 8 * (r >> 2) + (r & 3) + 4 * hi;
-                const unsigned char* vrow = vb + key * A::VROW + l31 * 4;
+            for (int dt0 = 0; dt0 < DV / 32; dt0 += 2) {
+                f32x16_t tsum[2];
 #pragma unroll
-                for (int dt = 0; dt < DV / 32; ++dt)
-                    acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(*reinterpret_cast<const float*>(vrow + dt * 128), s[0][r], acc[dt], 0, 0, 0);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 8 * (r >> 2) + (r & 3) + 4 * hi;
+                    const unsigned char* vrow = vb + key * A::VROW + l31 * 4;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        f32x16_t c;
+                        if (r == 0) {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) c[e] = 0.f;
+                        } else {
+                            c = tsum[q];
+                        }
+                        tsum[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(*reinterpret_cast<const float*>(vrow + (dt0 + q) * 128), s[0][r], c, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    acc[dt0 + q] += tsum[q];
+                    asm volatile("" : "+v"(acc[dt0 + q]));           // keep the add here (see mma_f32_chunk)
+                }
             }
         }
 
