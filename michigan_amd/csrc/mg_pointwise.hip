@@ -250,7 +250,11 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 {
     GRID_STRIDE(i, n) {
         const float gi = g[i] * gscale;
-        const float mi = m[i] + (gi - m[i]) * (1.f - b1);        // lerp form used by torch
+        // exp_avg.lerp_(grad, 1 - beta1) with torch's two-branch lerp (ATen Lerp.h): weight >= 0.5 evaluates end - (end - start) * (1 - weight).
+        // beta1 = 0 (the reference's TTUR setting, pix2pix_model.py:137-145) must give m = g EXACTLY: the one-branch form m + (g - m) rounds
+        // g away whenever |g| << |m| (m = last step's gradient), and g / (|g| + eps) -- a sign function here -- then steps on the rounding.
+        const float w = 1.f - b1, mo = b1 == 0.f ? 0.f : m[i];
+        const float mi = w < 0.5f ? mo + w * (gi - mo) : gi - (gi - mo) * (1.f - w);
         const float vi = v[i] * b2 + gi * gi * (1.f - b2);
         m[i] = mi; v[i] = vi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;

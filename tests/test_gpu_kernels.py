@@ -353,6 +353,20 @@ def test_blend_and_adam(dt):
             q.grad = gr.cuda()
             opt.step()
         _close("adam vs torch.optim", hip[0], q.data, 1e-6)
+        # beta1 = 0 (the reference's TTUR setting): exp_avg must be the gradient EXACTLY, also when this step's gradient is many orders
+        # of magnitude below the previous one (torch's two-branch lerp: g - (g - m) * 0; the one-branch form m + (g - m) rounds g away
+        # and the sign-like update g / (|g| + eps) then steps on the rounding)
+        grs = [torch.randn(10007, generator=g), torch.randn(10007, generator=g) * 1e-9, torch.randn(10007, generator=g) * 1e-3]
+        pc, mc, vc = p.clone().cuda(), torch.zeros(10007, device="cuda"), torch.zeros(10007, device="cuda")
+        q = torch.nn.Parameter(p.clone().cuda())
+        opt = torch.optim.Adam([q], lr=1e-3, betas=(0.0, 0.9))
+        for step, gr_ in enumerate(grs, 1):
+            ops.adam_step(pc, gr_.cuda(), mc, vc, lr=1e-3, beta1=0.0, beta2=0.9, eps=1e-8, step=step)
+            q.grad = gr_.cuda()
+            opt.step()
+            assert torch.equal(mc, gr_.cuda()), step
+            assert torch.equal(mc, opt.state[q]["exp_avg"]), step
+            _close("adam (changing gradient scale) vs torch.optim, step %d" % step, pc, q.data, 1e-6)
 
 
 def test_conv_matches_miopen_large_bf16():
