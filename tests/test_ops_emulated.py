@@ -277,3 +277,28 @@ def test_flatadam_adopts_gradients_detached_from_its_arena(emulator_backend):
         for a, b in zip(lin.parameters(), ref.parameters()):
             assert (a - b).abs().max().item() < 1e-6, it
             assert a.grad.data_ptr() == opt.flat_grad[opt._span_of[id(a)][0]:].data_ptr()
+
+
+def test_sync_bn_reference_clamp_switch(emulator_backend, monkeypatch):
+    """The reference's multi-device master computes inv_std = clamp(var, eps) ** -0.5 (sync_batchnorm/batchnorm.py:145), its one-device
+    path (F.batch_norm) and this repo at every world size (var + eps) ** -0.5.  MG_SYNCBN_REFERENCE_CLAMP=1 switches the data-parallel
+    statistics to the former; the default keeps N ranks == one rank on the concatenated batch."""
+    from michigan_amd import ops
+
+    class Done:                                     # a finished all-reduce
+        def wait(self):
+            pass
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 6, 5, 8, generator=g) * torch.tensor([1e-3, 0.5, 1, 2, 3, 4, 5, 6.0]) + 0.3
+    sums = ops.channel_sums(x, shift=True)
+    count, eps = float(x.numel() // 8), 1e-5
+    xr = x.double().reshape(-1, 8)
+    var = xr.var(0, unbiased=False)
+    _, rstd, _, _ = ops.batch_stats_finish((sums.clone(), Done(), count, 8), eps, 0.0)
+    assert torch.allclose(rstd.double(), (var + eps).rsqrt(), rtol=1e-6)
+    monkeypatch.setattr(ops, "SYNC_BN_REFERENCE_CLAMP", True)
+    _, rstd_c, _, _ = ops.batch_stats_finish((sums.clone(), Done(), count, 8), eps, 0.0)
+    assert torch.allclose(rstd_c.double(), var.clamp_min(eps).rsqrt(), rtol=1e-6)
+    assert not torch.allclose(rstd_c[:1].double(), rstd[:1].double(), rtol=1e-3)      # channel 0: var ~ 1e-6 < eps
+    _, rstd_1, _, _ = ops.batch_stats_finish((sums.clone(), None, count, 8), eps, 0.0)  # no reduction in flight: the one-device formula
+    assert torch.equal(rstd_1, rstd)
