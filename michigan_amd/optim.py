@@ -63,6 +63,7 @@ class FlatAdam:
         self._launched_any = False       # a bucket of this step is (or was) in flight
         self._synced = False             # sync_grads() already summed this step's gradients over the ranks
         self._consumed = False           # step() has applied them: gradients that arrive before the next zero_grad() are discardable
+        self._late_grads = False         # ... and some did arrive (data parallel): a second step() without zero_grad() would apply them rank-locally
         self._drained_local = False      # rank-local gradients were drained into flat_grad before any reduction (overlap off)
         # ---- autograd-path buckets (all parameters when the sink is off; unused otherwise) ---------------------
         # bucket = contiguous [lo, hi) slice of the arena; params were laid out in REVERSE registration
@@ -141,7 +142,7 @@ class FlatAdam:
                 p.grad = self.flat_grad[a:b].view(p.shape)
         self._pending = [b[2] for b in self.buckets]
         self._leftover = []
-        self._launched_any = self._drained_local = self._synced = self._consumed = False
+        self._launched_any = self._drained_local = self._synced = self._consumed = self._late_grads = False
 
     # ---- gradient sink: GEMM-order arena ------------------------------------------------------------
     def owns(self, p) -> bool:
@@ -156,7 +157,8 @@ class FlatAdam:
         if self._consumed:
             # a backward pass between step() and the next zero_grad() -- the reference's loop back-propagates the generator loss into D
             # after D.step() (pix2pix_trainer.py:64) and only D's next zero_grad() discards that: let autograd accumulate it into .grad,
-            # keep it out of the arena / the collectives
+            # keep it out of the arena / the collectives.  step() refuses to apply such a gradient.
+            self._late_grads = self._late_grads or self.dp
             return None
         if any(b is not None and not self.owns(b) for b in (b0, b1)):
             return None
@@ -304,6 +306,7 @@ class FlatAdam:
 
     def _on_grad(self, p):
         if self._consumed:
+            self._late_grads = True                     # (hooks exist only under data parallelism)
             return                                      # discardable gradient behind step(): no collective, no error (see grad_slot)
         if self._synced:
             raise RuntimeError(self._LATE_BACKWARD)
@@ -483,6 +486,11 @@ class FlatAdam:
                 p.grad = view
 
     def step(self):
+        if self.dp and self._consumed and self._late_grads:
+            # gradients arrived after the previous step() and no optimizer.zero_grad() came in between (net.zero_grad(), or backward + step
+            # twice): they were kept out of the collectives as discardable, so applying them now would be a rank-local update on top of the
+            # previous rank sum -- silent replica divergence.  The discard window ends at zero_grad(), not at the next step().
+            raise RuntimeError(self._LATE_BACKWARD)
         self._adopt_detached_grads()
         self.sync_grads()
         self.step_count += 1

@@ -5,8 +5,11 @@ this container so that its own modules can (a) pin oracle/michigan_oracle.py and
 The reference does not import as shipped here: torchvision,
 cv2 and dominate are missing and a few call sites hard-code ``.cuda()``.  This
 harness supplies stub modules and shims from the OUTSIDE; nothing under
-/root/reference is touched or copied.  /root/reference does not exist on the GPU
-box, so nothing that runs there may import this file.
+/root/reference is touched, and nothing of it enters the repository's history.
+/root/reference does not exist on the GPU box: there the same packages come from the
+git-ignored archive oracle/stage_reference.py writes (oracle/_ref/reference_py.zip, shipped
+with the snapshot like the built .so) -- used by tests/test_dropin.py[hip] and by bench.py's
+cpu_baseline leg only, never by the product path.
 """
 from __future__ import annotations
 
@@ -19,12 +22,25 @@ import torch
 import torch.nn as nn
 
 REFERENCE_ROOT = os.environ.get("MICHIGAN_REFERENCE", "/root/reference")
+# the same five packages as ONE git-ignored archive that travels to the GPU box with the snapshot (oracle/stage_reference.py)
+STAGED_ARCHIVE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "reference_py.zip")
 
 VGG19_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
 
 
-def reference_available() -> bool:
+def reference_checkout() -> bool:
+    """The reference's tree itself (datasets, samples, README included): the builder container."""
     return os.path.isdir(os.path.join(REFERENCE_ROOT, "models", "networks"))
+
+
+def reference_available() -> bool:
+    """The reference's Python packages can be imported: from the checkout, or from the staged archive (GPU box)."""
+    return reference_checkout() or os.path.isfile(STAGED_ARCHIVE)
+
+
+def reference_path() -> str:
+    """What goes on sys.path: the checkout where it exists, else the staged archive (zipimport)."""
+    return REFERENCE_ROOT if reference_checkout() else STAGED_ARCHIVE
 
 
 def _vgg19_stub(pretrained=False, **_):
@@ -133,15 +149,15 @@ def setup():
     if _ready:
         return
     if not reference_available():
-        raise RuntimeError(f"reference not found at {REFERENCE_ROOT}")
+        raise RuntimeError(f"reference not found at {REFERENCE_ROOT} (nor staged at {STAGED_ARCHIVE})")
     _install_stubs()
     if not torch.cuda.is_available():
         # loss.py hard-codes .cuda() / torch.cuda.FloatTensor; on a CPU-only host make them no-ops
         torch.Tensor.cuda = lambda self, *a, **k: self
         nn.Module.cuda = lambda self, *a, **k: self
         torch.cuda.FloatTensor = torch.FloatTensor
-    if REFERENCE_ROOT not in sys.path:
-        sys.path.insert(0, REFERENCE_ROOT)
+    if reference_path() not in sys.path:
+        sys.path.insert(0, reference_path())
     _adam_float_betas()
     import numpy as np
     if not hasattr(np, "float"):

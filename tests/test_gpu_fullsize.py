@@ -50,6 +50,40 @@ def test_generator_512_fp32_matches_oracle(hip_backend, full_generator):
     assert err < 1e-3
 
 
+@pytest.mark.parametrize("init", ["reference_default", "gain1"])
+def test_configs1_generator_forward_bs4_512_fp32_matches_oracle(hip_backend, init):
+    """BASELINE.json configs[1] AS STATED: SPADEB generator forward only, bs 4, 512x512, fp32, training-mode
+    batch statistics over the four images -- under the reference's default initialisation (xavier, 0.02: what `SPADEBGenerator(opt)`
+    builds, models/networks/base_network.py init_weights) and under the gain-1.0 synthetic state -- against the oracle on the host CPU
+    (~50 s on 32 cores each).  L_inf < 1e-3, the north-star bound; the measured value is printed."""
+    from michigan_amd import networks
+    from michigan_amd.model import default_options
+    from michigan_amd.synth import synth_batch, synth_state_dict
+    from oracle import michigan_oracle as O
+    opt = default_options(gpu_ids=[0], compute_dtype="fp32", random_expand_mask=False)
+    torch.manual_seed(3)
+    G = networks.SPADEBGenerator(opt).train()
+    if init == "reference_default":
+        G.init_weights(opt.init_type, opt.init_variance)
+        sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    else:
+        sd = synth_state_dict(G.state_dict(), seed=43, gain=1.0)
+        G.load_state_dict(sd)
+    G.cuda()
+    b = synth_batch(4, 512, seed=78)
+    random.seed(0)
+    with torch.no_grad():
+        out = _run(G, b, 4).float().cpu()
+        torch.set_num_threads(min(32, torch.get_num_threads()))
+        random.seed(0)
+        ref = O.spadeb_generator({k: v.cpu() for k, v in sd.items()}, opt, b["input_ref"], b["orient"], b["image_ref"], b["input_tag"],
+                                 b["noise"], b["image_tag"], True, {})
+    assert out.shape == ref.shape == (4, 3, 512, 512)
+    err = (out - ref).abs().max().item()
+    print(f"configs[1] (bs 4, 512x512, fp32, {init}) generator L_inf vs oracle: {err:.3e}; output range [{ref.min().item():.3f}, {ref.max().item():.3f}]")
+    assert err < 1e-3
+
+
 def test_forward_is_bitwise_deterministic_and_bf16_tracks_fp32(hip_backend, full_generator):
     opt, G, sd, b = full_generator
     outs = []
@@ -194,12 +228,22 @@ def test_generator_bf16_default_init_matches_oracle_tightly(hip_backend):
     assert err.max().item() < 6e-2 * rng
 
 
+# per-tensor band of the test below as measured in round 4 (gpurun_out/r04b/pytest_fullsize.log): (relative L2, cosine); allowed = + 20 %
+_BF16_ORACLE_BAND_R4 = {
+    "head_0.conv_0.weight_orig": (2.50e-1, 0.96851), "G_middle_1.conv_1.weight_orig": (2.05e-1, 0.97892),
+    "up_0.conv_0.weight_orig": (2.12e-1, 0.97745), "up_0.conv_s.weight_orig": (1.86e-1, 0.98254),
+    "up_0.norm_0.mlp_gamma.weight": (2.07e-1, 0.97854), "up_1.norm_1.mlp_beta.weight": (1.86e-1, 0.98261),
+    "head_0.norm_1.mlp_gamma.bias": (2.37e-1, 0.97169), "fc.layer5.weight": (2.96e-1, 0.95762),
+    "up_3.conv_1.bias": (6.94e-2, 0.99768), "up_2.norm_s.mlp_shared.0.weight": (1.34e-1, 0.99101),
+    "backgroud_enc.layer3.conv.weight": (1.84e-1, 0.98330)}
+
+
 def test_generator_fullwidth_bf16_gradients_track_fp32_oracle(hip_backend):
     """VERDICT r2 parity hole: the full-width gradient test above is fp32, so it runs `wgrad_kernel`; the BENCHMARKED weight-gradient
     kernel (`wgrad3x3_kernel`, bf16 only, split-K over 1024 / 512 channels) was covered at <= 256 channels.  Here: bf16 forward +
     backward at ngf 64, 256x256, batch 2 under the reference default init (the benchmarked configuration) against torch autograd
-    through the fp32 oracle, for the same 11 parameters.  The comparison is directional -- cosine similarity >= 0.95 and relative L2
-    error <= 0.35 per tensor: measured cos 0.961 ... 0.997, rel-L2 0.08 ... 0.28, the distance being bf16 rounding (2^-9 per value, ~40
+    through the fp32 oracle, for the same 11 parameters.  Per tensor, the band measured in round 4 + 20 % (_BF16_ORACLE_BAND_R4:
+    cos 0.958 ... 0.998, rel-L2 0.07 ... 0.30 -- was one directional bound, 0.95 / 0.35, for all), the distance being bf16 rounding (2^-9 per value, ~40
     layers each way) amplified by batch statistics over 2 x 4 x 4 = 32 values per channel at the latent (the fp32 kernels on the same
     problem are within 1e-2 of the float64 oracle, test above; a broken 1024-channel split-K would show as cos ~ 0 or a wrong scale).
     The weight-gradient kernels themselves are compared tightly at these channel counts against torch's fp32 GPU convolution in
@@ -237,8 +281,9 @@ def test_generator_fullwidth_bf16_gradients_track_fp32_oracle(hip_backend):
         cos = float(torch.dot(a, r) / (a.norm() * r.norm() + 1e-300))
         rel = float((a - r).norm() / (r.norm() + 1e-300))
         report[n] = "cos %.5f rel-L2 %.2e" % (cos, rel)
-        if not (cos >= 0.95 and rel <= 0.35):
-            bad[n] = report[n]
+        rel_r4, cos_r4 = _BF16_ORACLE_BAND_R4[n]
+        if not (cos >= 1.0 - 1.44 * (1.0 - cos_r4) and rel <= 1.2 * rel_r4):
+            bad[n] = report[n] + " (bounds: cos >= %.5f, rel-L2 <= %.3e)" % (1.0 - 1.44 * (1.0 - cos_r4), 1.2 * rel_r4)
     print("full-width bf16 gradients vs fp32 oracle:", report)
     assert not bad, bad
 
@@ -248,14 +293,25 @@ _WIDE = ["head_0.conv_0.weight_orig", "G_middle_1.conv_1.weight_orig", "up_0.con
          "up_3.conv_1.bias", "up_2.norm_s.mlp_shared.0.weight", "backgroud_enc.layer3.conv.weight"]
 
 
+# relative L2 / cosine of each tensor as measured in round 4 (gpurun_out/r04b/pytest_fullsize.log, same test, same seeds); the test
+# allows the measured band + 20 % per tensor (relative L2 x 1.2, hence 1 - cos x 1.44) instead of one round bound for all
+_BF16_STEP_BAND_R4 = {
+    "head_0.conv_0.weight_orig": (1.04e-1, 0.99453), "G_middle_1.conv_1.weight_orig": (6.16e-2, 0.99810),
+    "up_0.conv_0.weight_orig": (5.88e-2, 0.99827), "up_0.conv_s.weight_orig": (4.75e-2, 0.99887),
+    "up_0.norm_0.mlp_gamma.weight": (7.28e-2, 0.99735), "up_1.norm_1.mlp_beta.weight": (4.47e-2, 0.99901),
+    "head_0.norm_1.mlp_gamma.bias": (8.96e-2, 0.99598), "fc.layer5.weight": (1.17e-1, 0.99311),
+    "up_3.conv_1.bias": (1.47e-2, 0.99993), "up_2.norm_s.mlp_shared.0.weight": (3.49e-2, 0.99940),
+    "backgroud_enc.layer3.conv.weight": (3.96e-2, 0.99922)}
+
+
 def test_benchmark_config_bf16_step_tracks_fp32_step_on_the_hip_kernels(hip_backend):
     """no gradient check existed AT the benchmarked configuration.  BASELINE.json configs[2] as bench.py runs it
     -- bs 8, 512x512, ngf 64, reference default init (xavier 0.02), the full generator step (GAN + feature matching + VGG + orientation
     losses, gradient sink -> wgrad3x3 split-K) and the discriminator step -- once in bf16 and once in fp32 on the HIP kernels, same
     weights, same batch.  The fp32 HIP path is the pinned one (oracle / reference goldens; 512x512 forward test above), so it is the
-    yardstick here; no CPU oracle run is needed at this size.  Bounds: per-tensor cosine >= 0.99 and relative L2 <= 0.15 on the
-    generator gradients of the 11 wide parameters (measured 0.9931 ... 0.9999 / 1.5e-2 ... 1.2e-1: nine of the eleven meet the 0.995 / 0.1
-    VERDICT r3 asked for; the two that do not -- head_0.conv_0 0.9945 / 0.104, fc.layer5 0.9931 / 0.117 -- sit at the far end of the
+    yardstick here; no CPU oracle run is needed at this size.  Bounds: PER TENSOR, the band measured in round 4 + 20 %
+    (_BF16_STEP_BAND_R4: relative L2 1.5e-2 ... 1.2e-1, cosine 0.9931 ... 0.9999 on the generator gradients of the 11 wide parameters;
+    the two loosest -- head_0.conv_0 0.9945 / 0.104, fc.layer5 0.9931 / 0.117 -- sit at the far end of the
     backward pass, behind all seven blocks' bf16 activations and gradients, ~80 roundings of 2^-9 each way), every loss of the G and
     the D step within 2 % (of the loss or of 0.05 for the near-zero hinge terms; measured 1e-4).  The bs 2 / 256x256 comparison against the fp32 ORACLE (4x4 latent: 32 values per channel statistic) is
     test_generator_fullwidth_bf16_gradients_track_fp32_oracle above -- its measured band is printed there."""
@@ -288,8 +344,9 @@ def test_benchmark_config_bf16_step_tracks_fp32_step_on_the_hip_kernels(hip_back
         cos = float(torch.dot(a, r) / (a.norm() * r.norm() + 1e-300))
         rel = float((a - r).norm() / (r.norm() + 1e-300))
         report[n] = "cos %.5f rel-L2 %.2e" % (cos, rel)
-        if not (cos >= 0.99 and rel <= 0.15):
-            bad[n] = report[n]
+        rel_r4, cos_r4 = _BF16_STEP_BAND_R4[n]
+        if not (cos >= 1.0 - 1.44 * (1.0 - cos_r4) and rel <= 1.2 * rel_r4):
+            bad[n] = report[n] + " (bounds: cos >= %.5f, rel-L2 <= %.3e)" % (1.0 - 1.44 * (1.0 - cos_r4), 1.2 * rel_r4)
     print("bs 8 / 512x512 bf16 vs fp32 (HIP) generator-step gradients:", report)
     print("losses fp32:", l32)
     print("losses bf16:", l16)

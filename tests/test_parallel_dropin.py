@@ -277,11 +277,18 @@ def _late_backward_worker(rank, world, port, q):
     before = dict(parallel.COLLECTIVES)
     fwd_bwd()                                          # late: behind step(), before zero_grad()
     late_collectives = parallel.COLLECTIVES["grad_bucket"] - before["grad_bucket"]
+    # ... but a second step() WITHOUT zero_grad() (module.zero_grad(), or backward + step twice) would apply these rank-local,
+    # never-reduced gradients on top of the previous rank sum: it has to raise, not diverge silently
+    try:
+        optim.step()
+        second_step_raised = False
+    except RuntimeError as e:
+        second_step_raised = "zero_grad" in str(e)
     optim.zero_grad()                                  # discards it
     assert float(optim.flat_grad.abs().max()) == 0.0
     fwd_bwd()
     optim.step()
-    q.put((rank, {"late_collectives": late_collectives, "weights": optim.flat.numpy().copy()}))
+    q.put((rank, {"late_collectives": late_collectives, "second_step_raised": second_step_raised, "weights": optim.flat.numpy().copy()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -291,6 +298,7 @@ def test_flatadam_backward_between_step_and_zero_grad_is_discarded():
     import numpy as np
     got = _run(_late_backward_worker, 2)
     assert got[0]["late_collectives"] == 0 and got[1]["late_collectives"] == 0
+    assert got[0]["second_step_raised"] is True and got[1]["second_step_raised"] is True
     assert np.array_equal(got[0]["weights"], got[1]["weights"])
 
 
