@@ -402,7 +402,7 @@ def main():
             out["extra"] = {"configs1_generator_forward_fp32": gfwd_fp32_leg(a, local)}
         if world == 1 and not a.no_cpu_baseline and a.mode == "train":
             from oracle.cpu_baseline import bounded_baseline, reference_baseline
-            ref = reference_baseline(a.size)                   # the UNMODIFIED reference, where its checkout exists (never on the driver's GPU box)
+            ref = reference_baseline(a.size)                   # the UNMODIFIED reference: its checkout (builder container) or the archive oracle/stage_reference.py staged into the snapshot (GPU box)
             if ref is not None:
                 ips, threads, what = ref
                 out["cpu_baseline"] = {"value": round(ips, 4), "unit": "images/s", "cores": threads, "kind": "reference", "sample": what}

@@ -453,6 +453,68 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int,
     return _wgrad_launch(x, dy, fwd_taps(kh, kw, pad), stride, want_bias)
 
 
+# ---- weight gradients on a side HIP stream ------------------------------------------------------------------------------------
+# A weight gradient is a LEAF of the backward pass: nothing reads it before the optimiser's gradient drain.  The data-gradient chain it
+# hangs off alternates MFMA-bound convolutions with HBM-bound passes (SPADE's reduce / apply, activation and pooling adjoints: ~7 ms of
+# a 65 ms step) during which the matrix pipes idle, and every launch of the chain ends in a tail of half-empty CUs.  With
+# MG_WGRAD_STREAM=1 the gradient sink's wgrad launches go to a second stream: ordered behind the producer of dy by an event, joined
+# by the main stream before anything reads or re-zeroes the GEMM-order arena (FlatAdam.drain_grads / sync_grads / zero_grad), their
+# operands kept alive by record_stream.  Same kernels, same atomics: results are those of the in-stream order up to atomic order.
+WGRAD_SIDE_STREAM = os.environ.get("MG_WGRAD_STREAM", "0") == "1"
+_WGRAD_STREAMS = {}            # device index -> [stream, dirty]
+
+
+WGRAD_STREAM_PRIORITY = os.environ.get("MG_WGRAD_STREAM_PRIO", "low")      # "low": the least HIP stream priority of the device; "normal": torch's default
+
+
+def _new_side_stream(device):
+    """A stream for leaf work that must never delay the critical path: the LOWEST priority the device offers, so that whenever both
+    queues have workgroups to place the dispatcher serves the main stream first (torch.cuda.Stream only exposes normal / high)."""
+    if WGRAD_STREAM_PRIORITY == "low":
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            least, greatest, st = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_void_p()
+            with torch.cuda.device(device):
+                if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) == 0 and least.value != greatest.value \
+                        and hip.hipStreamCreateWithPriority(ctypes.byref(st), ctypes.c_uint(1), ctypes.c_int(least.value)) == 0 and st.value:
+                    return torch.cuda.ExternalStream(st.value, device=device)         # lives as long as the process
+        except (OSError, AttributeError):
+            pass
+    return torch.cuda.Stream(device=device)
+
+
+def _wgrad_side(device):
+    ent = _WGRAD_STREAMS.get(device.index)
+    if ent is None:
+        ent = _WGRAD_STREAMS[device.index] = [_new_side_stream(device), False]
+    return ent
+
+
+def wgrad_join(device=None):
+    """The current stream waits for every weight-gradient launch issued to the side stream so far (no-op when none was)."""
+    for idx, ent in _WGRAD_STREAMS.items():
+        if ent[1] and (device is None or device.index == idx):
+            torch.cuda.current_stream(ent[0].device).wait_stream(ent[0])
+            ent[1] = False
+
+
+def sink_wgrad(arena, slot, x, dy, kh, kw, stride, pad, need_b):
+    """Weight gradient of one convolution into its slot of the optimiser's GEMM-order arena (+ the bucket bookkeeping)."""
+    if WGRAD_SIDE_STREAM and x.is_cuda:
+        ent = _wgrad_side(x.device)
+        side = ent[0]
+        side.wait_stream(torch.cuda.current_stream(x.device))          # dy (and x) were produced on the current stream
+        with torch.cuda.stream(side):
+            conv_wgrad(x, dy, kh, kw, stride, pad, want_bias=need_b, out=(slot[1], slot[2]))
+            arena.slot_written(slot[0])                                # a bucket all-reduce it triggers is ordered behind the side stream
+        ent[1] = True
+        x.record_stream(side)
+        dy.record_stream(side)
+        return
+    conv_wgrad(x, dy, kh, kw, stride, pad, want_bias=need_b, out=(slot[1], slot[2]))
+    arena.slot_written(slot[0])
+
+
 def _wgrad_swapped(stride: int, cg8: int, cin: int) -> bool:
     return stride == 1 and cg8 <= 8 and cin >= 32
 
@@ -568,8 +630,7 @@ class _Conv2dFn(torch.autograd.Function):
             slot = arena.grad_slot(w_leaf, None, b_leaf if need_b else None, None, kh * kw, dpre8.shape[3], cx, sn)
         if slot is not None:
             # gradient sink: the wgrad kernel accumulates into the optimiser's GEMM-order arena; nothing goes through autograd
-            conv_wgrad(x, dpre8, kh, kw, stride, pad, want_bias=need_b, out=(slot[1], slot[2]))
-            arena.slot_written(slot[0])
+            sink_wgrad(arena, slot, x, dpre8, kh, kw, stride, pad, need_b)
         elif ctx.needs_input_grad[1]:
             res = conv_wgrad(x, dpre8, kh, kw, stride, pad, want_bias=need_b)
             if need_b:
@@ -926,8 +987,7 @@ class _SpadeFn(torch.autograd.Function):
             slot = arena.grad_slot(w_gamma, w_beta, ctx.sink[2] if need_b else None, ctx.sink[3] if need_b else None,
                                    kh * kh, rows, actv.shape[3], None)
         if slot is not None:
-            conv_wgrad(actv, dgb, kh, kh, 1, pad, want_bias=need_b, out=(slot[1], slot[2]))
-            arena.slot_written(slot[0])
+            sink_wgrad(arena, slot, actv, dgb, kh, kh, 1, pad, need_b)
         elif need_w:
             res = conv_wgrad(actv, dgb, kh, kh, 1, pad, want_bias=need_b)
             dwg, dwb = unpack_wgrad(res[0] if need_b else res, w_gamma.shape, two=True)
@@ -1022,8 +1082,7 @@ class _SpadePairFn(torch.autograd.Function):
             if sink is not None and need_w and ctx.needs_input_grad[base + 1] and ctx.needs_input_grad[base + 3]:
                 slot = sink[0].grad_slot(wg, wb, sink[2] if need_b else None, sink[3] if need_b else None, kh * kh, rows, actv.shape[3], None)
             if slot is not None:
-                conv_wgrad(actv, dgbs[b], kh, kh, 1, pad, want_bias=need_b, out=(slot[1], slot[2]))
-                sink[0].slot_written(slot[0])
+                sink_wgrad(sink[0], slot, actv, dgbs[b], kh, kh, 1, pad, need_b)
             elif need_w:
                 res = conv_wgrad(actv, dgbs[b], kh, kh, 1, pad, want_bias=need_b)
                 grads[base + 1], grads[base + 3] = unpack_wgrad(res[0] if need_b else res, wg.shape, two=True)

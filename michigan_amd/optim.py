@@ -135,6 +135,7 @@ class FlatAdam:
         self._wait_collectives()                     # of a backward whose gradients are being discarded
         self.flat_grad.zero_()
         if self.gemm is not None and any(s.written for s in self._slot_list):      # a backward without a step(): discard it
+            ops.wgrad_join(self.gemm.device)
             self.gemm[:self._gemm_used].zero_()
             self._reset_step_state()
         for p, (a, b) in zip(self._order, self._spans):                # re-attach if autograd swapped .grad
@@ -264,6 +265,7 @@ class FlatAdam:
         """GEMM-order arena -> reference-layout gradient arena (+=), spectral-norm backward included; re-zeroes what it read."""
         if self.gemm is None or not any(s.written for s in self._slot_list):
             return
+        ops.wgrad_join(self.gemm.device)                        # weight-gradient launches on the side stream (ops.sink_wgrad)
         if self._layout_dirty:
             self._freeze_layout()
         if self._table_event is not None:
@@ -351,6 +353,8 @@ class FlatAdam:
         scatter = None
         if self.dp and self._synced:
             return                                   # idempotent: step() after an explicit sync_grads() / finalize_grads()
+        if self.gemm is not None:
+            ops.wgrad_join(self.gemm.device)         # the arena is complete before anything below reduces or drains it
         if self.dp and (not self.overlap or self._drained_local):
             # not overlapped (gradient accumulation, or rank-local gradients already sit in flat_grad): drain what is local, then reduce
             # the reference-layout arena itself -- correct for any number of backward() calls

@@ -45,12 +45,14 @@ def time_train_step(size: int = 512, n: int = 1, threads: int | None = None, ite
     train = lambda sd: [v for v in sd.values() if v.requires_grad]
     opt_g = torch.optim.Adam(train(sdg), lr=opt.lr / 2, betas=(0.0, 0.9))
     opt_d = torch.optim.Adam(train(sdd), lr=opt.lr * 2, betas=(0.0, 0.9))
-    t0 = time.perf_counter()
+    times = []
     for it in range(warmup + iters):
-        if it == warmup:
-            t0 = time.perf_counter()
+        t0 = time.perf_counter()
         _one_iteration(sdg, sdd, sdv, opt, b, opt_g, opt_d)
-    return (time.perf_counter() - t0) / iters, n, threads
+        if it >= warmup:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    return times[len(times) // 2], n, threads           # the median iteration (one sample moved +-15 % between rounds)
 
 
 def _one_iteration(sdg, sdd, sdv, opt, b, opt_g, opt_d):
@@ -88,8 +90,9 @@ def bounded_baseline(full_size: int = 512, budget_s: float = 40.0):
     if small == full_size or secs * ratio * 2 > budget_s:
         return n / (secs * ratio), threads, (f"{what} at {small}x{small}, 1 timed iteration after 1 warm-up: {secs:.1f} s, "
                                              f"scaled x{ratio:.0f} pixels to {full_size}x{full_size}")
-    secs, n, threads = time_train_step(size=full_size, n=1, iters=1, warmup=1)
-    return n / secs, threads, f"{what} at {full_size}x{full_size}, 1 timed iteration after 1 warm-up: {secs:.1f} s"
+    iters = 3 if secs * ratio * 4.5 <= 1.5 * budget_s else 1
+    secs, n, threads = time_train_step(size=full_size, n=1, iters=iters, warmup=1)
+    return n / secs, threads, f"{what} at {full_size}x{full_size}, median of {iters} timed iteration(s) after 1 warm-up: {secs:.1f} s"
 
 
 def reference_baseline(full_size: int = 512, budget_s: float = 60.0):
@@ -129,7 +132,7 @@ def _reference_child(full_size: int, budget_s: float):
     R.setup()
     from trainers.pix2pix_trainer import Pix2PixTrainer                     # the reference's own
 
-    def run(size):
+    def run(size, timed=1):
         with tempfile.TemporaryDirectory() as ck:
             argv = ["--name", "timing", "--batchSize", "1", "--gpu_ids", "-1", "--load_size", str(size), "--crop_size", str(size),
                     "--checkpoints_dir", ck] + list(R.README_TRAIN_FLAGS)
@@ -138,15 +141,17 @@ def _reference_child(full_size: int, budget_s: float):
             with contextlib.redirect_stdout(sys.stderr):
                 trainer = Pix2PixTrainer(opt)
             data = synth_loader_batch(1, size, seed=1234)
-            secs = 0.0
-            for it in range(2):                                             # 1 warm-up + 1 timed
+            times = []
+            for it in range(1 + timed):                                     # 1 warm-up + `timed` iterations, the median reported
                 random.seed(it)
                 t0 = time.perf_counter()
                 with contextlib.redirect_stdout(sys.stderr):
                     trainer.run_generator_one_step(dict(data))
                     trainer.run_discriminator_one_step(dict(data))
-                secs = time.perf_counter() - t0
-            return secs
+                if it:
+                    times.append(time.perf_counter() - t0)
+            times.sort()
+            return times[len(times) // 2]
     what = "unmodified reference trainer (G step + D step, README flags + --no_lab_loss, fp32), bs=1"
     small = min(256, full_size)
     secs = run(small)
@@ -154,6 +159,7 @@ def _reference_child(full_size: int, budget_s: float):
     if small == full_size or secs * ratio * 2 > budget_s:
         out = (1 / (secs * ratio), f"{what} at {small}x{small}, 1 timed iteration after 1 warm-up: {secs:.1f} s, scaled x{ratio:.0f} pixels to {full_size}x{full_size}")
     else:
-        secs = run(full_size)
-        out = (1 / secs, f"{what} at {full_size}x{full_size}, 1 timed iteration after 1 warm-up: {secs:.1f} s")
+        timed = 3 if secs * ratio * 4.5 <= 1.5 * budget_s else 1
+        secs = run(full_size, timed)
+        out = (1 / secs, f"{what} at {full_size}x{full_size}, median of {timed} timed iteration(s) after 1 warm-up: {secs:.1f} s")
     print(json.dumps({"ips": out[0], "threads": threads, "what": out[1]}))

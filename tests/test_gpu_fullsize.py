@@ -87,6 +87,13 @@ def test_configs1_generator_forward_bs4_512_fp32_matches_oracle(hip_backend, ini
 def test_forward_is_bitwise_deterministic_and_bf16_tracks_fp32(hip_backend, full_generator):
     opt, G, sd, b = full_generator
     outs = []
+    # (a module's very FIRST forward takes the per-layer spectral-norm path that records the launch geometries; every later one the
+    # batched path, whose sums run in another order: warm the module so that the two compared runs are the steady-state path whatever
+    # test ran before this one -- round 5's `-k` selection put this test first and tripped over exactly that)
+    G.load_state_dict(sd)
+    G.train().set_compute_dtype(torch.float32)
+    with torch.no_grad():
+        _run(G, b, 2)
     for dt in (torch.float32, torch.float32, torch.bfloat16):
         G.load_state_dict(sd)                      # reset running stats / spectral-norm vectors
         G.train().set_compute_dtype(dt)
