@@ -461,6 +461,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int,
 # by the main stream before anything reads or re-zeroes the GEMM-order arena (FlatAdam.drain_grads / sync_grads / zero_grad), their
 # operands kept alive by record_stream.  Same kernels, same atomics: results are those of the in-stream order up to atomic order.
 WGRAD_SIDE_STREAM = os.environ.get("MG_WGRAD_STREAM", "0") == "1"
+SIDE_BRANCH = os.environ.get("MG_SIDE_BRANCH", "0") == "1"        # ... and SPADE's conditioning branch (side_branch below)
 _WGRAD_STREAMS = {}            # device index -> [stream, dirty]
 
 
@@ -522,7 +523,7 @@ def side_branch(fn, *inputs):
     gradient) then runs beside the main chain (dx: reduce -> all-reduce -> apply -> conv_1's dgrad ...) instead of inside it; forward,
     the thin conv overlaps the statistics pass of x.  `inputs` were produced on the current stream.  Returns fn()'s tensor, marked."""
     dev = inputs[0].device
-    if not (WGRAD_SIDE_STREAM and inputs[0].is_cuda and torch.is_grad_enabled()):
+    if not (WGRAD_SIDE_STREAM and SIDE_BRANCH and inputs[0].is_cuda and torch.is_grad_enabled()):
         return fn()
     main = torch.cuda.current_stream(dev)
     side = _wgrad_side(dev)[0]

@@ -40,13 +40,13 @@ def test_trainer_with_weight_gradients_on_the_side_stream_matches_reference_gold
     numbers at the same tolerances as the in-stream order (fixture B: --use_ig, two G+D iterations, weights and statistics compared);
     and the side stream must really have been used."""
     from michigan_amd import ops
-    prev = ops.WGRAD_SIDE_STREAM
-    ops.WGRAD_SIDE_STREAM = True
+    prev = ops.WGRAD_SIDE_STREAM, ops.SIDE_BRANCH
+    ops.WGRAD_SIDE_STREAM = ops.SIDE_BRANCH = True           # SIDE_BRANCH: SPADE's conditioning branch and its adjoint over there too
     try:
         rec, gold = _run("B", "fp32")
         assert ops._WGRAD_STREAMS and all(not ent[1] for ent in ops._WGRAD_STREAMS.values())     # created, used, and joined at the end
     finally:
-        ops.WGRAD_SIDE_STREAM = prev
+        ops.WGRAD_SIDE_STREAM, ops.SIDE_BRANCH = prev
     TP.compare(rec, gold, rtol_loss0=5e-4, rtol_later=RTOL_LATER_HIP, atol_img=1e-3, atol_weight=2 * 4e-4 * 2 + 1e-5)
 
 

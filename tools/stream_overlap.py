@@ -51,11 +51,14 @@ def company(s, e):
         if a >= e: break
         tot += min(b, e) - max(a, s)
     return tot
-cls = defaultdict(lambda: [0, 0, 0])
+cls = defaultdict(lambda: [0, 0, 0, 0, 0, 0, 0])          # time, company, n, [alone: time, n], [mostly with company: time, n]
 for s, e, q, name in rows:
     if q != main_q: continue
-    key = name.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:60]
-    c = cls[key]; c[0] += e - s; c[1] += company(s, e); c[2] += 1
+    key = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    key = key.split("(")[0][:70]
+    c = cls[key]; co = company(s, e); c[0] += e - s; c[1] += co; c[2] += 1
+    if co < 0.1 * (e - s): c[3] += e - s; c[4] += 1
+    elif co > 0.9 * (e - s): c[5] += e - s; c[6] += 1
 print(f"main queue {main_q}: kernel classes by time, and the share of it spent beside a side-queue kernel")
-for k, (t, c, n) in sorted(cls.items(), key=lambda kv: -kv[1][0])[:28]:
-    print(f"  {t / 1e6:8.2f} ms  {100.0 * c / max(t, 1):5.1f} % with company  {n:5d} x  {k}")
+for k, (t, c, n, ta, na, tc, nc) in sorted(cls.items(), key=lambda kv: -kv[1][0])[:32]:
+    print(f"  {t / 1e6:8.2f} ms  {100.0 * c / max(t, 1):5.1f} % with company  {n:5d} x  mean alone {ta / max(na, 1) / 1e3:8.1f} us ({na}) / beside a side kernel {tc / max(nc, 1) / 1e3:8.1f} us ({nc})  {k}")
