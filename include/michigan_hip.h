@@ -490,8 +490,6 @@ int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* o
  * 18 = stages a split of the generic weight-gradient kernel keeps at least (default 32).
  * 20 = the three-resident 3x3 halo kernel (128 channels x 12x16 pixels, three workgroups per CU; bf16): 0 off, 1 where the
  *      128 x 16x16 tile would be chosen, 2 every eligible launch; 21 = ... only for Cin <= value.  Bitwise the same outputs as key 20 = 0.
- * 22 = bytes of LDS the 3x3 weight-gradient kernel requests at least (0 = what it needs; > 81920 caps it at one workgroup per CU so
- *      that a second stream keeps half of every CU: weight gradients on a side stream, michigan_amd/ops.py sink_wgrad).
  * Results agree within accumulation-order rounding whatever the setting (each setting is bit-reproducible except
  * the weight gradients, which use fp32 atomics).
  * MEASUREMENT builds (wrong or no results, timing only; tools/probe_halo.py, tools/probe_wgrad3x3.py): key 10 = 1..6 variants of the big

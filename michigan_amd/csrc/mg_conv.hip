@@ -23,7 +23,6 @@ int g_mg_conv_bigtiles = 1;      // allow the 128x256 / 256x256 tiles (mg_set_op
 extern int g_mg_wgrad3x3;          // mg_wgrad.hip (mg_set_option(3, v))
 extern int g_mg_norm_bwd_vec;      // mg_norm.hip (mg_set_option(19, v))
 extern int g_mg_wgrad_min_stages;  // mg_wgrad.hip (mg_set_option(18, v))
-extern int g_mg_wgrad_lds_floor;   // mg_wgrad.hip (mg_set_option(22, bytes))
 extern int g_mg_conv_thin;         // mg_conv_thin.hip (mg_set_option(6, v))
 extern int g_mg_conv_dot;          // mg_conv_dot.hip (mg_set_option(8, v))
 int g_mg_conv_noxpre = 0;        // mg_set_option(15, 1): A/B switch, the SPADE halo kernel loads x in its epilogue instead of ahead of the main loop
@@ -612,7 +611,6 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 7 && (value == 0 || value == 1)) { g_mg_conv_wide = value; return MG_OK; }
     if (key == 8 && value >= 0 && value <= 2) { g_mg_conv_dot = value; return MG_OK; }
     if (key == 20 && value >= 0 && value <= 2) { g_mg_conv_halo3 = value; return MG_OK; }
-    if (key == 22 && value >= 0 && value <= 96 * 1024) { g_mg_wgrad_lds_floor = value; return MG_OK; }
     if (key == 21 && value >= 32) { g_mg_conv_halo3_maxcin = value; return MG_OK; }
 #if MG_PROBES
     // measurement builds only (python tools/build_variant.py probes mg_conv.hip mg_conv_halo.hip mg_wgrad3x3.hip -DMG_PROBES=1): truncated /

@@ -17,7 +17,6 @@
 
 int g_mg_wgrad3x3 = 1;     // mg_set_option(3, v): 0 = always the generic tap-per-workgroup kernel
 
-int g_mg_wgrad_lds_floor = 0;         // mg_set_option(22, bytes): the 3x3 weight-gradient kernel requests at least this much LDS (occupancy cap: > 80 KiB = one workgroup per CU)
 int g_mg_wgrad_min_stages = 32;      // mg_set_option(18, v): stages (of 32 / 16 pixels) a split of the generic kernel keeps at least
 
 namespace {

@@ -16,7 +16,6 @@
 #include "mg_conv_common.h"
 #include "mg_wgrad_common.h"
 
-extern int g_mg_wgrad_lds_floor;   // mg_wgrad.hip, mg_set_option(22, bytes)
 extern int g_mg_wgrad3x3_probe;    // mg_conv.hip, mg_set_option(12, v): 1 = launch the stamped build of wgrad3x3_kernel<2, 2>
 
 namespace {
@@ -317,11 +316,7 @@ int launch3(Wg3K& k, hipStream_t st, int* nsplit, bool dry)
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_wgrad: bad grid %ld", nblk);
     auto kern = wgrad3x3_kernel<MT, NT, W16>;
     static bool attr_done = false;
-    constexpr size_t LDS_CAP = LDS > 96 * 1024 ? LDS : 96 * 1024;
-    if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_CAP); attr_done = true; }
-    // mg_set_option(22, bytes): request at least that much LDS -- more than half a CU's 160 KiB leaves ONE workgroup of this kernel per CU
-    // and the other half of the CU (registers, LDS, wave slots) to whatever the other stream runs (ops.sink_wgrad: weight gradients on the side stream)
-    const size_t lds_req = (size_t)g_mg_wgrad_lds_floor > LDS ? ((size_t)g_mg_wgrad_lds_floor < LDS_CAP ? (size_t)g_mg_wgrad_lds_floor : LDS_CAP) : LDS;
+    if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr_done = true; }
 #if MG_PROBES
     if constexpr (MT == 2 && NT == 2 && !W16) {
         if (g_mg_wgrad3x3_probe) {
@@ -334,7 +329,7 @@ int launch3(Wg3K& k, hipStream_t st, int* nsplit, bool dry)
         }
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_req, st, k);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), LDS, st, k);
     MG_CHECK_LAUNCH("mg_conv_wgrad(3x3)");
     return MG_OK;
 }

@@ -66,7 +66,7 @@ class SPADE(nn.Module):
         n, h, w, c = x.shape
         seg = segmap.at(h, w) if isinstance(segmap, SegPyramid) else SegPyramid(segmap, x.dtype).at(h, w)
         pending = self.param_free_norm.statistics_begin(x, stats)      # sums + async all-reduce (data parallel)
-        actv = ops.side_branch(lambda: self.mlp_shared[0](seg, act=ops.ACT_RELU), seg)   # independent of the statistics: overlaps with it
+        actv = self.mlp_shared[0](seg, act=ops.ACT_RELU)               # independent of the statistics: overlaps with it
         st = self.param_free_norm.statistics_finish(pending)
         mean, rstd, count = st[0], st[1], st[2]
         out = ops.spade_modulate(x, actv, self.mlp_gamma.weight, self.mlp_gamma.bias,
@@ -84,8 +84,8 @@ def spade_pair(norm_a: SPADE, norm_b: SPADE, x, segmap, acts, up: bool = False):
     bn_a, bn_b = norm_a.param_free_norm, norm_b.param_free_norm
     if bn_a.training:
         pending = ops.batch_stats_begin(x, up=up)                          # sums + async all-reduce (data parallel)
-        actv_a = ops.side_branch(lambda: norm_a.mlp_shared[0](seg, act=ops.ACT_RELU), seg)      # independent of the statistics: overlap with it
-        actv_b = ops.side_branch(lambda: norm_b.mlp_shared[0](seg, act=ops.ACT_RELU), seg)
+        actv_a = norm_a.mlp_shared[0](seg, act=ops.ACT_RELU)               # independent of the statistics: overlap with it
+        actv_b = norm_b.mlp_shared[0](seg, act=ops.ACT_RELU)
         mean, rstd, count, sums = ops.batch_stats_finish(pending, bn_a.eps, bn_a.momentum, bn_a.running_mean, bn_a.running_var)
         with torch.no_grad():
             ops.advance_running_stats(sums, count, bn_b.eps, bn_b.momentum, bn_b.running_mean, bn_b.running_var)

@@ -456,12 +456,16 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int,
 # ---- weight gradients on a side HIP stream ------------------------------------------------------------------------------------
 # A weight gradient is a LEAF of the backward pass: nothing reads it before the optimiser's gradient drain.  The data-gradient chain it
 # hangs off alternates MFMA-bound convolutions with HBM-bound passes (SPADE's reduce / apply, activation and pooling adjoints: ~7 ms of
-# a 65 ms step) during which the matrix pipes idle, and every launch of the chain ends in a tail of half-empty CUs.  With
-# MG_WGRAD_STREAM=1 the gradient sink's wgrad launches go to a second stream: ordered behind the producer of dy by an event, joined
-# by the main stream before anything reads or re-zeroes the GEMM-order arena (FlatAdam.drain_grads / sync_grads / zero_grad), their
-# operands kept alive by record_stream.  Same kernels, same atomics: results are those of the in-stream order up to atomic order.
-WGRAD_SIDE_STREAM = os.environ.get("MG_WGRAD_STREAM", "0") == "1"
-SIDE_BRANCH = os.environ.get("MG_SIDE_BRANCH", "0") == "1"        # ... and SPADE's conditioning branch (side_branch below)
+# a 65 ms step) during which the matrix pipes idle, and every launch of the chain ends in a tail of half-empty CUs.  The gradient
+# sink's wgrad launches therefore go to a second, lowest-priority stream: ordered behind the producer of dy by an event, joined by the
+# main stream before anything reads or re-zeroes the GEMM-order arena (FlatAdam.drain_grads / sync_grads / zero_grad), their operands
+# kept alive by record_stream.  Same kernels, same atomics: results are those of the in-stream order up to atomic order.
+# Measured (round 5, bs 8 / 512^2 / bf16, A B A B in one process, profiles/r05_side_stream_ab.txt): 65.1 -> 63.6 ms per step (-2.2 %),
+# 39.3 -> 37.6 at bs 4; the kernel trace (profiles/r05_stream_overlap.txt) has two queues busy 29 % of the time.  What did NOT pay on
+# top of it, same A/B: capping the side kernels at one workgroup per CU (LDS request > 80 KiB: 63.8 / 63.3), and moving SPADE's whole
+# conditioning branch (mlp_shared forward, the gamma|beta data gradient and its adjoint) over as well (65.0: the step's critical path
+# then waits for side-stream work it used to run itself).  MG_WGRAD_STREAM=0 restores the single stream.
+WGRAD_SIDE_STREAM = os.environ.get("MG_WGRAD_STREAM", "1") != "0"
 _WGRAD_STREAMS = {}            # device index -> [stream, dirty]
 
 
@@ -514,48 +518,6 @@ def sink_wgrad(arena, slot, x, dy, kh, kw, stride, pad, need_b):
         return
     conv_wgrad(x, dy, kh, kw, stride, pad, want_bias=need_b, out=(slot[1], slot[2]))
     arena.slot_written(slot[0])
-
-
-def side_branch(fn, *inputs):
-    """Forward of a branch of the graph that is a LEAF of the backward pass -- SPADE's conditioning branch: segmentation map ->
-    mlp_shared conv + ReLU -> actv -- on the side stream.  Autograd runs a node's backward on the stream its forward ran on, so the
-    whole adjoint of the branch (the gamma|beta conv's data gradient that _SpadeFn computes for it, the ReLU mask, mlp_shared's weight
-    gradient) then runs beside the main chain (dx: reduce -> all-reduce -> apply -> conv_1's dgrad ...) instead of inside it; forward,
-    the thin conv overlaps the statistics pass of x.  `inputs` were produced on the current stream.  Returns fn()'s tensor, marked."""
-    dev = inputs[0].device
-    if not (WGRAD_SIDE_STREAM and SIDE_BRANCH and inputs[0].is_cuda and torch.is_grad_enabled()):
-        return fn()
-    main = torch.cuda.current_stream(dev)
-    side = _wgrad_side(dev)[0]
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        out = fn()
-    main.wait_stream(side)                    # (forward: nothing else is queued on the side stream)
-    for t in inputs:
-        t.record_stream(side)
-    out.record_stream(main)
-    out._mg_side = True
-    return out
-
-
-def _actv_flags(a) -> int:
-    """bit 0: `a` is a ReLU output whose mask the consumer's data gradient may fold; bit 1: `a` was produced by side_branch()."""
-    return (1 if getattr(a, "_mg_relu_out", False) else 0) | (2 if getattr(a, "_mg_side", False) else 0)
-
-
-def _branch_dgrad(on_side: bool, dgb, wt, kh, pad, hw, cin, relu_mask):
-    """Data gradient of the gamma|beta conv = the gradient of actv.  When actv came from side_branch() its consumer (mlp_shared's
-    backward node) runs on the side stream, so this launch goes there too: ordered behind the reduce pass that wrote dgb."""
-    if on_side and WGRAD_SIDE_STREAM and dgb.is_cuda:
-        ent = _wgrad_side(dgb.device)
-        ent[0].wait_stream(torch.cuda.current_stream(dgb.device))
-        with torch.cuda.stream(ent[0]):
-            d = conv_dgrad(dgb, wt, kh, kh, 1, pad, hw, cin, relu_mask=relu_mask)
-        ent[1] = True
-        dgb.record_stream(ent[0])
-        wt.record_stream(ent[0])
-        return d
-    return conv_dgrad(dgb, wt, kh, kh, 1, pad, hw, cin, relu_mask=relu_mask)
 
 
 def _wgrad_swapped(stride: int, cg8: int, cin: int) -> bool:
@@ -969,7 +931,7 @@ def _interleave32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 class _SpadeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, act, slope, actv_relu=False, sink=None):
-        ctx.actv_relu, ctx.actv_side = bool(int(actv_relu) & 1), bool(int(actv_relu) & 2)      # _actv_flags
+        ctx.actv_relu = bool(actv_relu)
         ctx.sink = sink
         x, actv = _nhwc(x), _nhwc(actv)
         n, h, w, c = x.shape
@@ -1019,8 +981,8 @@ class _SpadeFn(torch.autograd.Function):
             work = _sync_bn_all_reduce(sums, "syncbn_bwd")    # overlaps with the gamma/beta conv's backward below
         if ctx.needs_input_grad[1]:
             wt = pack_weight(w_gamma, w_beta, x.dtype, _roundup(actv.shape[3], 128), rows, 1)
-            dactv = _branch_dgrad(ctx.actv_side, dgb, wt, kh, pad, (hh, ww), actv.shape[3],
-                                  actv if (ctx.actv_relu and FUSE_RELU_MASK) else None)             # mlp_shared's ReLU (normalization.py:94-99)
+            dactv = conv_dgrad(dgb, wt, kh, kh, 1, pad, (hh, ww), actv.shape[3],
+                               relu_mask=actv if (ctx.actv_relu and FUSE_RELU_MASK) else None)      # mlp_shared's ReLU (normalization.py:94-99)
         need_w = ctx.needs_input_grad[2] or ctx.needs_input_grad[4]
         need_b = ctx.needs_input_grad[3] or ctx.needs_input_grad[5]
         db = None
@@ -1080,8 +1042,7 @@ class _SpadePairFn(torch.autograd.Function):
             g1s.append(g1)
         if need:
             ctx.save_for_backward(x, actv0, wg0, wb0, outs[0], g1s[0], actv1, wg1, wb1, outs[1], g1s[1], mean, rstd)
-        ctx.cfg = (count, (act0, act1), slope, bool(up), (bool(int(relu0) & 1), bool(int(relu1) & 1)), sinks, (h, w))
-        ctx.sides = (bool(int(relu0) & 2), bool(int(relu1) & 2))                       # _actv_flags: actv came from side_branch()
+        ctx.cfg = (count, (act0, act1), slope, bool(up), (bool(relu0), bool(relu1)), sinks, (h, w))
         return outs[0], outs[1]
 
     @staticmethod
@@ -1118,8 +1079,8 @@ class _SpadePairFn(torch.autograd.Function):
             pad = kh // 2
             if ctx.needs_input_grad[base]:
                 wt = pack_weight(wg, wb, x.dtype, _roundup(actv.shape[3], 128), rows, 1)
-                grads[base] = _branch_dgrad(ctx.sides[b], dgbs[b], wt, kh, pad, (hh, ww), actv.shape[3],
-                                            actv if (relus[b] and FUSE_RELU_MASK) else None)
+                grads[base] = conv_dgrad(dgbs[b], wt, kh, kh, 1, pad, (hh, ww), actv.shape[3],
+                                         relu_mask=actv if (relus[b] and FUSE_RELU_MASK) else None)
             need_w = ctx.needs_input_grad[base + 1] or ctx.needs_input_grad[base + 3]
             need_b = ctx.needs_input_grad[base + 2] or ctx.needs_input_grad[base + 4]
             sink, slot, db = sinks[b], None, None
@@ -1164,7 +1125,7 @@ def spade_modulate_pair(x, mods, mean, rstd, count, *, acts, slope=0.2, up=False
     sk0, sk1 = _sink_for(wg0, bg0, wb0, bb0), _sink_for(wg1, bg1, wb1, bb1)
     sinks = (None if sk0 is None else (sk0[0], sk0[1], bg0, bb0), None if sk1 is None else (sk1[0], sk1[1], bg1, bb1))
     return _SpadePairFn.apply(x, a0, wg0, bg0, wb0, bb0, a1, wg1, bg1, wb1, bb1, mean, rstd, count, acts[0], acts[1], slope, bool(up),
-                              _actv_flags(a0), _actv_flags(a1), sinks)
+                              getattr(a0, "_mg_relu_out", False), getattr(a1, "_mg_relu_out", False), sinks)
 
 
 def spade_modulate(x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, *, act=ACT_NONE, slope=0.2):
@@ -1176,7 +1137,7 @@ def spade_modulate(x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count,
     """
     sk = _sink_for(w_gamma, b_gamma, w_beta, b_beta)
     return _SpadeFn.apply(x, actv, w_gamma, b_gamma, w_beta, b_beta, mean, rstd, count, act, slope,
-                          _actv_flags(actv), None if sk is None else (sk[0], sk[1], b_gamma, b_beta))
+                          getattr(actv, "_mg_relu_out", False), None if sk is None else (sk[0], sk[1], b_gamma, b_beta))
 
 
 # ----------------------------------------------------------------------------

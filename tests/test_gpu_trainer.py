@@ -35,18 +35,18 @@ def test_trainer_fp32_matches_reference_trainer_golden(hip_backend, tag):
 
 
 def test_trainer_with_weight_gradients_on_the_side_stream_matches_reference_golden(hip_backend):
-    """MG_WGRAD_STREAM=1 (ops.sink_wgrad): the gradient sink's wgrad launches on a second HIP stream -- event-ordered behind the producer of
+    """ops.sink_wgrad (the default; MG_WGRAD_STREAM=0 turns it off): the gradient sink's wgrad launches on a second HIP stream -- event-ordered behind the producer of
     dy, joined before the arena is drained / reduced / re-zeroed, operands held by record_stream -- must give the reference trainer's
     numbers at the same tolerances as the in-stream order (fixture B: --use_ig, two G+D iterations, weights and statistics compared);
     and the side stream must really have been used."""
     from michigan_amd import ops
-    prev = ops.WGRAD_SIDE_STREAM, ops.SIDE_BRANCH
-    ops.WGRAD_SIDE_STREAM = ops.SIDE_BRANCH = True           # SIDE_BRANCH: SPADE's conditioning branch and its adjoint over there too
+    prev = ops.WGRAD_SIDE_STREAM
+    ops.WGRAD_SIDE_STREAM = True
     try:
         rec, gold = _run("B", "fp32")
         assert ops._WGRAD_STREAMS and all(not ent[1] for ent in ops._WGRAD_STREAMS.values())     # created, used, and joined at the end
     finally:
-        ops.WGRAD_SIDE_STREAM, ops.SIDE_BRANCH = prev
+        ops.WGRAD_SIDE_STREAM = prev
     TP.compare(rec, gold, rtol_loss0=5e-4, rtol_later=RTOL_LATER_HIP, atol_img=1e-3, atol_weight=2 * 4e-4 * 2 + 1e-5)
 
 

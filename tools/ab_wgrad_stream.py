@@ -6,7 +6,6 @@ os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(64 << 20))
 import michigan_amd  # noqa: F401
 import torch
 from michigan_amd import ops
-import michigan_amd._cabi
 from michigan_amd.model import Pix2PixTrainer, default_options
 from michigan_amd.synth import synth_batch
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 8
@@ -17,17 +16,12 @@ def step():
     tr.run_generator_one_step(data); tr.run_discriminator_one_step(data)
 for _ in range(3): step()
 print(f"# bs {bs}, side-stream priority {ops.WGRAD_STREAM_PRIORITY}")
-be = michigan_amd._cabi.backend()
-CASES = [("in-stream", False, False, 0), ("wgrad on side", True, False, 0), ("wgrad on side, 1 workgroup/CU", True, False, 84 * 1024),
-         ("wgrad + SPADE branch on side", True, True, 0), ("wgrad + branch on side, 1 workgroup/CU", True, True, 84 * 1024)]
-for rep in range(3):
-    for name, side, branch, floor in CASES:
-        ops.WGRAD_SIDE_STREAM, ops.SIDE_BRANCH = side, branch
-        be.mg_set_option(22, floor)
+for rep in range(4):
+    for v in (False, True):
+        ops.WGRAD_SIDE_STREAM = v
         step(); torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(6): step()
         torch.cuda.synchronize()
-        print(f"{name:42s}: {(time.perf_counter() - t0) / 6 * 1e3:.2f} ms/step", flush=True)
-be.mg_set_option(22, 0)
+        print(f"weight gradients on the side stream = {v}: {(time.perf_counter() - t0) / 6 * 1e3:.2f} ms/step", flush=True)
 ent = list(ops._WGRAD_STREAMS.values())
 print("side stream:", ent[0][0] if ent else None, "priority", getattr(ent[0][0], "priority", "?") if ent else "")
