@@ -488,8 +488,6 @@ int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* o
  * 9 = weight-slab ring depth of the big halo tile (3 default, or 4); 15 = 1: the SPADE halo kernel loads x in its epilogue instead of
  * ahead of its K loop (default 0); 17 = 1: two K slices also for 161..320-workgroup launches with >= 256 K steps (default 0);
  * 18 = stages a split of the generic weight-gradient kernel keeps at least (default 32).
- * 20 = the three-resident 3x3 halo kernel (128 channels x 12x16 pixels, three workgroups per CU; bf16): 0 off, 1 where the
- *      128 x 16x16 tile would be chosen, 2 every eligible launch; 21 = ... only for Cin <= value.  Bitwise the same outputs as key 20 = 0.
  * Results agree within accumulation-order rounding whatever the setting (each setting is bit-reproducible except
  * the weight gradients, which use fp32 atomics).
  * MEASUREMENT builds (wrong or no results, timing only; tools/probe_halo.py, tools/probe_wgrad3x3.py): key 10 = 1..6 variants of the big

@@ -27,8 +27,6 @@ extern int g_mg_conv_thin;         // mg_conv_thin.hip (mg_set_option(6, v))
 extern int g_mg_conv_dot;          // mg_conv_dot.hip (mg_set_option(8, v))
 int g_mg_conv_noxpre = 0;        // mg_set_option(15, 1): A/B switch, the SPADE halo kernel loads x in its epilogue instead of ahead of the main loop
 int g_mg_conv_dbg_noepi = 0;     // MEASUREMENT ONLY (mg_set_option(10, 1)): the halo kernel returns before its epilogue -- wrong results, main-loop time
-extern int g_mg_conv_halo3;        // mg_conv_halo3.hip (mg_set_option(20, v))
-int g_mg_conv_halo3_maxcin = 1 << 20;   // mg_set_option(21, v): the three-resident kernel only for Cin <= v (short-K layers are where the hidden epilogue pays)
 int g_mg_conv_wide = 1;          // bf16 epilogues store 16 bytes per lane after a half-wave quad exchange (mg_set_option(7, v))
 int g_mg_conv_pipeline = 1;      // 0 = register-staged double buffer, 1 = LDS-DMA 3-stage ring (mg_set_option(0, v))
 
@@ -533,18 +531,7 @@ int dispatch_conv(ConvK& k, int epilogue, hipStream_t st)
     if (conv_thin_taps_applies(k, ET<T>::DT, epilogue)) return launch_conv_thin_taps(k, st);
     if (conv_dot_applies(k, ET<T>::DT, epilogue)) return launch_conv_dot(k, ET<T>::DT, st);
     if (conv_fewout_applies(k, ET<T>::DT, epilogue)) return launch_conv_fewout(k, st);
-    if (halo_applies<T>(k)) {
-        // three-resident halo kernel (mg_conv_halo3.hip): bf16, > 64 GEMM rows, forward or mirrored tap order, lean epilogue case
-        if constexpr (sizeof(T) == 2) {
-            if (g_mg_conv_halo3 && k.Cout_gemm > 64 && k.Hin >= 12 && conv_halo3_epilogue_ok(k, epilogue)) {
-                const long big = (long)k.N * ((k.Hin + 15) / 16) * ((k.Win + 15) / 16) * ((k.Cout_gemm + 127) / 128);
-                const int order = conv_halo3_taporder(k);
-                if (order && (g_mg_conv_halo3 == 2 || (g_mg_conv_halo_big && k.Hin >= 16 && big >= 1024 && k.Cin <= g_mg_conv_halo3_maxcin)))
-                    return launch_conv_halo3(k, epilogue, order, st);
-            }
-        }
-        return launch_conv_halo(k, ET<T>::DT, epilogue, st);
-    }
+    if (halo_applies<T>(k)) return launch_conv_halo(k, ET<T>::DT, epilogue, st);
     return epilogue == MG_EPI_SPADE ? dispatch_tiles<T, MG_EPI_SPADE>(k, st) : dispatch_tiles<T, MG_EPI_PLAIN>(k, st);
 }
 
@@ -610,8 +597,6 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 19 && (value == 0 || value == 1)) { g_mg_norm_bwd_vec = value; return MG_OK; }
     if (key == 7 && (value == 0 || value == 1)) { g_mg_conv_wide = value; return MG_OK; }
     if (key == 8 && value >= 0 && value <= 2) { g_mg_conv_dot = value; return MG_OK; }
-    if (key == 20 && value >= 0 && value <= 2) { g_mg_conv_halo3 = value; return MG_OK; }
-    if (key == 21 && value >= 32) { g_mg_conv_halo3_maxcin = value; return MG_OK; }
 #if MG_PROBES
     // measurement builds only (python tools/build_variant.py probes mg_conv.hip mg_conv_halo.hip mg_wgrad3x3.hip -DMG_PROBES=1): truncated /
     // stamped variants of the big halo tile and of wgrad3x3_kernel, their stamp buffer, the SPADE x prefetch off

@@ -707,9 +707,6 @@ struct LinearPixMap {
 }  // namespace
 
 int launch_conv_halo(ConvK& k, int dtype, int epilogue, hipStream_t st);   // mg_conv_halo.hip
-int conv_halo3_taporder(const ConvK& k);                                     // mg_conv_halo3.hip: 0 = not its case, 1 = forward, 2 = mirrored taps
-bool conv_halo3_epilogue_ok(const ConvK& k, int epilogue);
-int launch_conv_halo3(ConvK& k, int epilogue, int taporder, hipStream_t st);
 bool conv_thin_applies(const ConvK& k, int dtype, int epilogue);            // mg_conv_thin.hip
 int launch_conv_thin(ConvK& k, hipStream_t st);
 bool conv_thin_taps_applies(const ConvK& k, int dtype, int epilogue);       // mg_conv_thin.hip: any <= 7x7 window, stride 1 | 2

@@ -798,54 +798,6 @@ def test_wide_epilogue_stores_are_bit_identical_to_quad_stores(epi):
         assert torch.equal(a.view(torch.int16), b_.view(torch.int16))
 
 
-def test_halo3_is_bit_identical_to_the_two_resident_halo_kernel():
-    """mg_set_option(20, 2): the three-resident 3x3 halo kernel (mg_conv_halo3.hip: 128 channels x 12x16 pixels, piece-major LDS patch,
-    two-slot weight ring, block-wise epilogue) against the kernels it replaces (mg_conv_halo.hip) -- same K order, same epilogue
-    arithmetic, so the SAME BITS: SPADE forward (h and the saved 1 + gamma reach the comparison through dx / dactv), plain convs with
-    bias + LeakyReLU / residual, and the data gradients (mirrored taps, folded ReLU mask), on chip-filling, ragged (H % 12, W % 16,
-    channel tails) and multi-chunk (Cin = 64 ... 256) geometries.  Weight gradients are excluded: fp32 atomics."""
-    from michigan_amd import _cabi, ops
-    be = _cabi.backend()
-    runs = []
-    for v in (0, 2):
-        be.mg_set_option(20, v)
-        try:
-            res = []
-            for (n, h, w, cin, c) in [(2, 48, 64, 128, 64), (1, 37, 50, 64, 96), (2, 24, 16, 128, 40), (1, 131, 96, 256, 128)]:
-                gg = torch.Generator().manual_seed(n * h + c)
-                x = (torch.randn(n, h, w, c, generator=gg) * 1.5 + 0.3).bfloat16().cuda().requires_grad_()
-                actv = torch.randn(n, h, w, cin, generator=gg).clamp_min(0).bfloat16().cuda().requires_grad_()
-                actv._mg_relu_out = True                      # a ReLU output: its data gradient folds the mask (the AUX = mask epilogue body)
-                wg = (torch.randn(c, cin, 3, 3, generator=gg) / 34).cuda().requires_grad_()
-                wb = (torch.randn(c, cin, 3, 3, generator=gg) / 34).cuda().requires_grad_()
-                bg = (torch.randn(c, generator=gg) * 0.1).cuda().requires_grad_()
-                bb = (torch.randn(c, generator=gg) * 0.1).cuda().requires_grad_()
-                gh = torch.randn(n, h, w, c, generator=gg).bfloat16().cuda()
-                mean, rstd, cnt, _ = ops.batch_stats(x)
-                hh = ops.spade_modulate(x, actv, wg, bg, wb, bb, mean, rstd, cnt, act=ops.ACT_LRELU)
-                dx, dactv = torch.autograd.grad(hh, (x, actv), gh)
-                res += [hh.detach().clone(), dx.detach().clone(), dactv.detach().clone()]
-                # plain convs: bias + LeakyReLU, then bias + residual; their data gradients
-                cout = 128 if c <= 64 else 160
-                xi = torch.randn(n, h, w, cin, generator=gg).bfloat16().cuda().requires_grad_()
-                w1 = (torch.randn(cout, cin, 3, 3, generator=gg) / (cin * 9) ** 0.5).cuda().requires_grad_()
-                b1 = torch.randn(cout, generator=gg).cuda().requires_grad_()
-                r = torch.randn(n, h, w, cout, generator=gg).bfloat16().cuda()
-                y1 = ops.conv2d(xi, w1, b1, padding=1, act=ops.ACT_LRELU)
-                y2 = ops.conv2d(xi, w1, b1, padding=1, resid=r)
-                g1 = torch.randn(n, h, w, cout, generator=gg).bfloat16().cuda()
-                dxi1, = torch.autograd.grad(y1, (xi,), g1, retain_graph=True)
-                dxi2, = torch.autograd.grad(y2, (xi,), g1)
-                res += [y1.detach().clone(), y2.detach().clone(), dxi1.detach().clone(), dxi2.detach().clone()]
-            torch.cuda.synchronize()
-            runs.append(res)
-        finally:
-            be.mg_set_option(20, 0)
-    assert len(runs[0]) == len(runs[1]) == 28
-    for i, (a, b_) in enumerate(zip(*runs)):
-        assert torch.equal(a.view(torch.int16), b_.view(torch.int16)), f"tensor {i}: {(a.float() - b_.float()).abs().max().item()}"
-
-
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_hinge_loss_and_wide_edge_weight_fused(dt):
     """mg_wide_edge_weight (bit-exact vs the reference's interpolate / max_pool2d formula, incl. the
