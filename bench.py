@@ -50,6 +50,11 @@ def parse():
     return ap.parse_args()
 
 
+def _streams_on() -> bool:
+    from michigan_amd import ops
+    return bool(ops.WGRAD_SIDE_STREAM)
+
+
 class ConvMeter:
     """HIP-event timing of every mg_conv_taps launch of one extra (untimed) training step, on the
     stream the kernels are launched on; algorithmic FLOPs from the launch geometry."""
@@ -82,10 +87,14 @@ class ConvMeter:
             gbytes = (inp.numel() + opix * streams + wt.numel()) * inp.element_size()
             recs.append((s, e, flops, inp.dtype, dominant, abytes, gbytes))
         self.ops._launch_conv = timed
+        # per-launch durations are a kernel's own only while nothing runs beside it: the instrumented step keeps the weight gradients on
+        # the main stream (the timed steps run them on the side stream, michigan_amd/ops.py sink_wgrad)
+        self._side, self.ops.WGRAD_SIDE_STREAM = self.ops.WGRAD_SIDE_STREAM, False
         return self
 
     def __exit__(self, *a):
         self.ops._launch_conv = self._orig
+        self.ops.WGRAD_SIDE_STREAM = self._side
 
     def summary(self):
         torch.cuda.synchronize()
@@ -383,7 +392,9 @@ def main():
                                    (f"SPADEB generator forward only (no_grad, train-mode BN), bs={a.batch_per_gpu}/GPU, "
                                     f"{a.size}x{a.size}, BASELINE.json configs[1]"),
                        "global_batch": gbatch, "batch_per_gpu": a.batch_per_gpu, "resolution": a.size,
-                       "parallelism": f"dp{world}", "init": "reference default (xavier, 0.02), random VGG weights"},
+                       "parallelism": f"dp{world}", "init": "reference default (xavier, 0.02), random VGG weights",
+                       "streams": ("weight gradients on a lowest-priority side stream (ops.sink_wgrad); roofline launch timings from one extra single-stream step"
+                                   if _streams_on() else "single stream (MG_WGRAD_STREAM=0)")},
             "step_tflops_effective": {"vs_reference_work": round(value * step_gflop_ref / 1e3 / world, 1),
                                       "vs_minimum_work": round(value * step_gflop_min / 1e3 / world, 1),
                                       "gflop_per_image": [step_gflop_ref, step_gflop_min], "unit": "TFLOP/s per GPU"},

@@ -520,6 +520,18 @@ def sink_wgrad(arena, slot, x, dy, kh, kw, stride, pad, need_b):
     arena.slot_written(slot[0])
 
 
+# SPADE's conditioning branch (segmentation map -> mlp_shared conv + ReLU -> actv) depends on the network INPUT only: the generator
+# issues all of them (18 / 36 thin convolutions, HBM-write-bound, ~1 ms per pass) to the side stream at the top of its forward, where
+# they run beside the encoders and the 8x8 ... 32x32 blocks -- launches that cannot fill 256 CUs on their own -- instead of inside the
+# main chain in front of every gamma|beta conv (networks/generator.py _prefetch_conditioning; MG_SPADE_PREFETCH=0: inline as before).
+SPADE_PREFETCH = os.environ.get("MG_SPADE_PREFETCH", "1") != "0"
+
+
+def side_stream(device):
+    """The lowest-priority stream for leaf / input-only work (shared with the weight gradients)."""
+    return _wgrad_side(device)[0]
+
+
 def _wgrad_swapped(stride: int, cg8: int, cin: int) -> bool:
     return stride == 1 and cg8 <= 8 and cin >= 32
 
