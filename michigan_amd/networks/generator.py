@@ -60,32 +60,6 @@ class SPADEBGenerator(BaseNetwork):
         sw = size // (2 ** ups[opt.num_upsampling_layers])
         return sw, round(sw / opt.aspect_ratio)
 
-    def _prefetch_conditioning(self, pyramid):
-        """Every SPADE layer's actv = ReLU(mlp_shared(seg)) depends on the conditioning pyramid only: compute them all NOW on the
-        side stream (ops.side_stream: lowest priority), in the order the blocks will ask for them, each with an event the consumer
-        waits on (normalization.conditioning).  The thin convolutions then run beside the encoders and the low-resolution blocks
-        instead of in front of every gamma|beta conv.  Autograd runs their (tiny) backward on the side stream as well."""
-        more = self.opt.num_upsampling_layers == "more"
-        level, plan = 0, []
-        for block, up in ((self.head_0, False), (self.G_middle_0, True), (self.G_middle_1, more),
-                          (self.up_0, True), (self.up_1, True), (self.up_2, True), (self.up_3, True)):
-            level += 1 if up else 0
-            norms = [block.norm_0] + ([block.norm_s] if block.learned_shortcut else []) + [block.norm_1]
-            plan += [(n, pyramid.at(self.sh << level, self.sw << level)) for n in norms]
-        if not plan:
-            return
-        dev = plan[0][1].device
-        main, side = torch.cuda.current_stream(dev), ops.side_stream(dev)
-        side.wait_stream(main)                                   # the pyramid and this step's packed weights were produced on the main stream
-        with torch.cuda.stream(side):
-            for norm, seg in plan:
-                actv = norm.mlp_shared[0](seg, act=ops.ACT_RELU)
-                ev = torch.cuda.Event()
-                ev.record(side)
-                norm.__dict__["_mg_actv"] = (actv, ev, tuple(seg.shape))
-        for seg in {id(s): s for _, s in plan}.values():
-            seg.record_stream(side)
-
     def forward(self, input=None, z=None, orient_mask=None, image_ref=None, input_tag=None, noise=None,
                 image_tag=None):
         spectral.prepare(self)            # every spectral-normed conv of this pass: power iteration + W / sigma + GEMM images, batched
@@ -134,8 +108,6 @@ class SPADEBGenerator(BaseNetwork):
             if cacheable:
                 self.__dict__["_mg_input_cache"] = (key, tuple(weakref.ref(t) for t in src if t is not None), pyramid, hair_masks)
 
-        if ops.SPADE_PREFETCH and x.is_cuda:
-            self._prefetch_conditioning(pyramid)
         back_feats, back_masks = self.backgroud_enc(image_tag, input_tag, noise)
 
         x = self.head_0(x, pyramid)

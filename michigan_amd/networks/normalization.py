@@ -36,19 +36,6 @@ class SegPyramid:
         return self._cache[key]
 
 
-def conditioning(norm: "SPADE", seg: torch.Tensor) -> torch.Tensor:
-    """actv = ReLU(mlp_shared(seg)) of one SPADE layer: the tensor the generator pre-computed on the side stream
-    (SPADEBGenerator._prefetch_conditioning: the current stream waits for its event), or computed here."""
-    pre = norm.__dict__.pop("_mg_actv", None)
-    if pre is not None:
-        actv, ev, shape = pre
-        if shape == tuple(seg.shape):
-            torch.cuda.current_stream(actv.device).wait_event(ev)
-            actv.record_stream(torch.cuda.current_stream(actv.device))      # allocated on the side stream, consumed here
-            return actv
-    return norm.mlp_shared[0](seg, act=ops.ACT_RELU)
-
-
 class SPADE(nn.Module):
     """Spatially-adaptive normalisation, one fused launch per layer.
 
@@ -79,7 +66,7 @@ class SPADE(nn.Module):
         n, h, w, c = x.shape
         seg = segmap.at(h, w) if isinstance(segmap, SegPyramid) else SegPyramid(segmap, x.dtype).at(h, w)
         pending = self.param_free_norm.statistics_begin(x, stats)      # sums + async all-reduce (data parallel)
-        actv = conditioning(self, seg)                                 # independent of the statistics: overlaps with it
+        actv = self.mlp_shared[0](seg, act=ops.ACT_RELU)               # independent of the statistics: overlaps with it
         st = self.param_free_norm.statistics_finish(pending)
         mean, rstd, count = st[0], st[1], st[2]
         out = ops.spade_modulate(x, actv, self.mlp_gamma.weight, self.mlp_gamma.bias,
@@ -97,8 +84,8 @@ def spade_pair(norm_a: SPADE, norm_b: SPADE, x, segmap, acts, up: bool = False):
     bn_a, bn_b = norm_a.param_free_norm, norm_b.param_free_norm
     if bn_a.training:
         pending = ops.batch_stats_begin(x, up=up)                          # sums + async all-reduce (data parallel)
-        actv_a = conditioning(norm_a, seg)                                 # independent of the statistics: overlap with it
-        actv_b = conditioning(norm_b, seg)
+        actv_a = norm_a.mlp_shared[0](seg, act=ops.ACT_RELU)               # independent of the statistics: overlap with it
+        actv_b = norm_b.mlp_shared[0](seg, act=ops.ACT_RELU)
         mean, rstd, count, sums = ops.batch_stats_finish(pending, bn_a.eps, bn_a.momentum, bn_a.running_mean, bn_a.running_var)
         with torch.no_grad():
             ops.advance_running_stats(sums, count, bn_b.eps, bn_b.momentum, bn_b.running_mean, bn_b.running_var)

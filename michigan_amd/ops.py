@@ -464,7 +464,8 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int,
 # 39.3 -> 37.6 at bs 4; the kernel trace (profiles/r05_stream_overlap.txt) has two queues busy 29 % of the time.  What did NOT pay on
 # top of it, same A/B: capping the side kernels at one workgroup per CU (LDS request > 80 KiB: 63.8 / 63.3), and moving SPADE's whole
 # conditioning branch (mlp_shared forward, the gamma|beta data gradient and its adjoint) over as well (65.0: the step's critical path
-# then waits for side-stream work it used to run itself).  MG_WGRAD_STREAM=0 restores the single stream.
+# then waits for side-stream work it used to run itself), or only its forward half, all 36 mlp_shared convs prefetched on the side stream
+# at the top of the generator pass (+0.4 ms).  MG_WGRAD_STREAM=0 restores the single stream.
 WGRAD_SIDE_STREAM = os.environ.get("MG_WGRAD_STREAM", "1") != "0"
 _WGRAD_STREAMS = {}            # device index -> [stream, dirty]
 
@@ -518,18 +519,6 @@ def sink_wgrad(arena, slot, x, dy, kh, kw, stride, pad, need_b):
         return
     conv_wgrad(x, dy, kh, kw, stride, pad, want_bias=need_b, out=(slot[1], slot[2]))
     arena.slot_written(slot[0])
-
-
-# SPADE's conditioning branch (segmentation map -> mlp_shared conv + ReLU -> actv) depends on the network INPUT only: the generator
-# issues all of them (18 / 36 thin convolutions, HBM-write-bound, ~1 ms per pass) to the side stream at the top of its forward, where
-# they run beside the encoders and the 8x8 ... 32x32 blocks -- launches that cannot fill 256 CUs on their own -- instead of inside the
-# main chain in front of every gamma|beta conv (networks/generator.py _prefetch_conditioning; MG_SPADE_PREFETCH=0: inline as before).
-SPADE_PREFETCH = os.environ.get("MG_SPADE_PREFETCH", "1") != "0"
-
-
-def side_stream(device):
-    """The lowest-priority stream for leaf / input-only work (shared with the weight gradients)."""
-    return _wgrad_side(device)[0]
 
 
 def _wgrad_swapped(stride: int, cg8: int, cin: int) -> bool:
