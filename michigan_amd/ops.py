@@ -467,9 +467,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int,
 # then waits for side-stream work it used to run itself), or only its forward half, all 36 mlp_shared convs prefetched on the side stream
 # at the top of the generator pass (+0.4 ms).  MG_WGRAD_STREAM=0 restores the single stream.
 WGRAD_SIDE_STREAM = os.environ.get("MG_WGRAD_STREAM", "1") != "0"
-_WGRAD_STREAMS = {}            # device index -> [stream, dirty]
-
-
+_WGRAD_STREAMS = {}            # device index -> [stream, dirty, held]: held = [(event, x, dy)] of launches that may still be running
 WGRAD_STREAM_PRIORITY = os.environ.get("MG_WGRAD_STREAM_PRIO", "low")      # "low": the least HIP stream priority of the device; "normal": torch's default
 
 
@@ -492,30 +490,40 @@ def _new_side_stream(device):
 def _wgrad_side(device):
     ent = _WGRAD_STREAMS.get(device.index)
     if ent is None:
-        ent = _WGRAD_STREAMS[device.index] = [_new_side_stream(device), False]
+        ent = _WGRAD_STREAMS[device.index] = [_new_side_stream(device), False, []]
     return ent
 
 
 def wgrad_join(device=None):
-    """The current stream waits for every weight-gradient launch issued to the side stream so far (no-op when none was)."""
+    """The current stream waits for every weight-gradient launch issued to the side stream so far (no-op when none was).  Behind the
+    join the operands may be freed or rewritten by the current stream again: the references held for them are dropped."""
     for idx, ent in _WGRAD_STREAMS.items():
         if ent[1] and (device is None or device.index == idx):
             torch.cuda.current_stream(ent[0].device).wait_stream(ent[0])
             ent[1] = False
+            ent[2].clear()
 
 
 def sink_wgrad(arena, slot, x, dy, kh, kw, stride, pad, need_b):
     """Weight gradient of one convolution into its slot of the optimiser's GEMM-order arena (+ the bucket bookkeeping)."""
     if WGRAD_SIDE_STREAM and x.is_cuda:
         ent = _wgrad_side(x.device)
-        side = ent[0]
+        side, held = ent[0], ent[2]
         side.wait_stream(torch.cuda.current_stream(x.device))          # dy (and x) were produced on the current stream
         with torch.cuda.stream(side):
             conv_wgrad(x, dy, kh, kw, stride, pad, want_bias=need_b, out=(slot[1], slot[2]))
             arena.slot_written(slot[0])                                # a bucket all-reduce it triggers is ordered behind the side stream
+            ev = torch.cuda.Event()
+            ev.record(side)
         ent[1] = True
-        x.record_stream(side)
-        dy.record_stream(side)
+        # The operands stay REFERENCED until their launch has finished (or the main stream has joined).  That keeps their memory from
+        # being reused -- and it keeps autograd from accumulating into dy IN PLACE: a conv's dy is also the gradient of its residual
+        # input (returned as such by _ConvFn.backward), and the engine's input buffer adds the next incoming gradient into a tensor it
+        # holds the only reference to.  In stream order that write came after the wgrad's reads; beside a side stream it raced them
+        # (round 5: G_middle_1.conv_1's weight gradient at cosine 0.78 in tests/test_gpu_fullsize.py before this list existed).
+        while held and held[0][0].query():
+            held.pop(0)
+        held.append((ev, x, dy))
         return
     conv_wgrad(x, dy, kh, kw, stride, pad, want_bias=need_b, out=(slot[1], slot[2]))
     arena.slot_written(slot[0])

@@ -798,6 +798,49 @@ def test_wide_epilogue_stores_are_bit_identical_to_quad_stores(epi):
         assert torch.equal(a.view(torch.int16), b_.view(torch.int16))
 
 
+def test_side_stream_weight_gradient_survives_inplace_gradient_accumulation():
+    """ops.sink_wgrad: a conv's dy is ALSO the gradient of its residual input; the autograd engine adds the next gradient that arrives
+    for that input INTO the tensor it holds the last reference to.  In stream order that write follows the wgrad's reads; with the
+    weight gradient on the side stream it races them unless sink_wgrad keeps dy referenced until its launch has finished (round 5:
+    G_middle_1.conv_1's gradient came out at cosine 0.78 in the bs 8 / 512^2 test).  Here the side queue is made to LAG (a spin kernel
+    in front of it), a residual conv's input receives a second gradient, and the side-stream result must equal the in-stream one."""
+    from michigan_amd import ops
+    from michigan_amd.networks.layers import HipConv2d
+    from michigan_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(23)
+    conv = HipConv2d(128, 128, kernel_size=3, padding=1).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(128, 128, 3, 3, generator=g) / 34)
+        conv.bias.copy_(torch.randn(128, generator=g) * 0.1)
+    optim = FlatAdam(conv.parameters(), lr=1e-4)
+    x0 = torch.randn(4, 64, 64, 128, generator=g).bfloat16().cuda()
+    gy = torch.randn(4, 64, 64, 128, generator=g).bfloat16().cuda()
+    prev = ops.WGRAD_SIDE_STREAM
+    res = {}
+    try:
+        for side in (False, True, True):
+            ops.WGRAD_SIDE_STREAM = side
+            optim.zero_grad()
+            x = x0.clone().requires_grad_()
+            h = x * 1.0                                           # a non-leaf: its gradient is accumulated in the engine's input buffer
+            if side:
+                with torch.cuda.stream(ops._wgrad_side(x.device)[0]):
+                    torch.cuda._sleep(40_000_000)                # ~20 ms: every side-stream launch of this backward starts late
+            y = conv(h, resid=h)                                  # dy of the conv == gradient of `resid`, arrives first ...
+            z = y + h * 3.0                                       # ... then the second gradient for h is added to it
+            z.backward(gy)
+            optim.finalize_grads()
+            torch.cuda.synchronize()
+            res.setdefault(side, []).append((conv.weight.grad.detach().float().clone(), x.grad.detach().float().clone()))
+    finally:
+        ops.WGRAD_SIDE_STREAM = prev
+    (w0, dx0), = res[False]
+    for w1, dx1 in res[True]:
+        assert torch.equal(dx0, dx1)
+        rel = ((w1 - w0).norm() / w0.norm()).item()
+        assert rel < 1e-4, rel                                   # fp32 atomics in another order: ~1e-7; the race gave O(1)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_hinge_loss_and_wide_edge_weight_fused(dt):
     """mg_wide_edge_weight (bit-exact vs the reference's interpolate / max_pool2d formula, incl. the
