@@ -284,8 +284,7 @@ int launch_attention(const AttnArgs& a, hipStream_t st)
     using A = AT<T>;
     constexpr int LDS = 2 * (A::KVB * A::KROW + A::KVB * A::VROW);
     auto kern = self_attention_kernel<T>;
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr_done = true; }
+    mg_raise_lds_cap(reinterpret_cast<const void*>(kern), LDS);
     const dim3 grid((a.L + BQ - 1) / BQ, a.N);
     hipLaunchKernelGGL(kern, grid, dim3(NTHR_A), LDS, st, a);
     return 0;

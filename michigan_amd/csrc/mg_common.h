@@ -86,3 +86,20 @@ __device__ __forceinline__ float mg_act_grad_from_out(float y, int act, float sl
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize has to be raised once per (kernel, DEVICE): a process that drives several GPUs
+// (not the one-process-per-GPU layout of this package, but legal) must not skip the call on its second device.
+#include <mutex>
+static inline void mg_raise_lds_cap(const void* kern, int bytes)
+{
+    static std::mutex mu;
+    static struct { const void* k; int dev; int bytes; } seen[256];
+    static int nseen = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < nseen; ++i)
+        if (seen[i].k == kern && seen[i].dev == dev && seen[i].bytes >= bytes) return;
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (nseen < 256) { seen[nseen].k = kern; seen[nseen].dev = dev; seen[nseen].bytes = bytes; ++nseen; }
+}

@@ -467,8 +467,7 @@ int launch_conv_p(ConvK& k, hipStream_t st)
                 }
             }
             if (ldsr > 65536) {
-                static bool attr_done = false;       // raise the dynamic-LDS cap once per instantiation
-                if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr); attr_done = true; }
+                mg_raise_lds_cap(reinterpret_cast<const void*>(kern), (int)ldsr);       // once per instantiation and device
             }
             hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), ldsr, st, k);
             MG_CHECK_LAUNCH("mg_conv_taps(glds)");

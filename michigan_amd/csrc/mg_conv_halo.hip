@@ -397,8 +397,7 @@ int launch_halo_g(ConvK& k, hipStream_t st)
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_taps(halo): bad grid %ld", nblk);
     auto kern = conv3x3_halo_kernel<T, EPI, WM, NT, PROBE>;
     if constexpr (G::LDS > 65536) {
-        static bool attr_done = false;
-        if (!attr_done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); attr_done = true; }
+        mg_raise_lds_cap(reinterpret_cast<const void*>(kern), G::LDS);
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NTHR), G::LDS, st, k);
     MG_CHECK_LAUNCH("mg_conv_taps(halo)");

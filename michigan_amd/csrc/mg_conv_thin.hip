@@ -322,8 +322,7 @@ int launch_thin_taps(ConvK& k, const ThinTapsGeom& g, hipStream_t st)
     }
     for (int t = 0; t < MG_MAX_TAPS; ++t) k.tap[t] = ofs[t];
     auto kern = conv_thin_taps_kernel<CS, S>;
-    static bool attr_done = false;
-    if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr_done = true; }
+    mg_raise_lds_cap(reinterpret_cast<const void*>(kern), 80 * 1024);
     const long grid = g.ntiles < 512 ? g.ntiles : 512;           // 2 workgroups per CU, each walking tiles
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), g.lds, st, k, (int)g.ntiles, g.HH, g.HW, g.dy0, g.dx0, g.nsteps);
     MG_CHECK_LAUNCH("mg_conv_taps(thin, tap list)");

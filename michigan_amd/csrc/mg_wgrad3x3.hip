@@ -315,14 +315,12 @@ int launch3(Wg3K& k, hipStream_t st, int* nsplit, bool dry)
     if (dry) return MG_OK;
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_wgrad: bad grid %ld", nblk);
     auto kern = wgrad3x3_kernel<MT, NT, W16>;
-    static bool attr_done = false;
-    if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); attr_done = true; }
+    mg_raise_lds_cap(reinterpret_cast<const void*>(kern), (int)LDS);
 #if MG_PROBES
     if constexpr (MT == 2 && NT == 2 && !W16) {
         if (g_mg_wgrad3x3_probe) {
             auto pk = wgrad3x3_kernel<MT, NT, W16, true>;
-            static bool pattr = false;
-            if (!pattr) { hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS); pattr = true; }
+            mg_raise_lds_cap(reinterpret_cast<const void*>(pk), (int)LDS);
             hipLaunchKernelGGL(pk, dim3((unsigned)nblk), dim3(256), LDS, st, k);
             MG_CHECK_LAUNCH("mg_conv_wgrad(3x3 probe)");
             return MG_OK;

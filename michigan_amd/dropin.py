@@ -105,14 +105,29 @@ def _save_network_rank0(net, label, epoch, opt):
     import torch.distributed as dist
     rank, world = _rank_world()
     path = os.path.join(opt.checkpoints_dir, opt.name, "%s_net_%s.pth" % (epoch, label))
+    err = None
     if rank == 0:
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        sd = {k: v.detach().to("cpu", copy=True) for k, v in net.state_dict().items()}
         tmp = "%s.tmp.%d" % (path, os.getpid())
-        torch.save(sd, tmp)
-        os.replace(tmp, path)
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            sd = {k: v.detach().to("cpu", copy=True) for k, v in net.state_dict().items()}
+            torch.save(sd, tmp)
+            os.replace(tmp, path)
+        except Exception as e:                            # disk full, permissions ...: every rank has to learn about it
+            err = e
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     if world > 1:
-        dist.barrier()
+        # save() must be called on ALL ranks (like the reference's loop does): the outcome of rank 0's write is broadcast, so a failed
+        # write raises everywhere instead of leaving the other ranks in a barrier until the collective times out
+        dev = next(net.parameters()).device if dist.get_backend() == "nccl" else torch.device("cpu")
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev)
+        dist.broadcast(ok, src=0)
+        if int(ok.item()) == 0 and err is None:
+            raise RuntimeError("michigan_amd.dropin: rank 0 failed to write %s" % path)
+    if err is not None:
+        raise err
 
 
 class _EpochShardSampler(torch.utils.data.distributed.DistributedSampler):
@@ -145,7 +160,16 @@ def _sharded_create_dataloader(orig_module):
             raise ValueError("michigan_amd.dropin: --batchSize %d is the GLOBAL batch and must be a multiple of the %d ranks" % (opt.batchSize, world))
         print("dataset [%s] of size %d was created (rank %d of %d reads 1/%d of it, %d samples per batch)" %
               (type(instance).__name__, len(instance), rank, world, world, opt.batchSize // world))
-        sampler = _EpochShardSampler(instance, num_replicas=world, rank=rank, shuffle=not opt.serial_batches, drop_last=bool(opt.isTrain))
+        # one shuffle seed per JOB (rank 0's torch seed, broadcast), not DistributedSampler's constant 0: the reference's
+        # DataLoader(shuffle=True) draws a different order every run; drop_last only when training (no padded duplicates at test time
+        # would need a gather of uneven shards -- test-time loaders keep DistributedSampler's padding, documented in INTEGRATION.md)
+        import torch.distributed as dist
+        seed = torch.tensor([torch.initial_seed() % (1 << 31)], dtype=torch.int64)
+        if dist.get_backend() == "nccl":
+            seed = seed.cuda()
+        dist.broadcast(seed, src=0)
+        sampler = _EpochShardSampler(instance, num_replicas=world, rank=rank, shuffle=not opt.serial_batches, drop_last=bool(opt.isTrain),
+                                     seed=int(seed.item()))
         return torch.utils.data.DataLoader(instance, batch_size=opt.batchSize // world, sampler=sampler, num_workers=int(opt.nThreads),
                                            drop_last=bool(opt.isTrain))
     return create_dataloader
@@ -156,7 +180,7 @@ def _patch_job_side_effects():
     loading.  Patched in the reference's own modules when they are importable; what stays the user's job is listed in INTEGRATION.md
     (visualiser / loss-log output of `train.py` -- guard it with `if rank == 0` or accept one copy per rank)."""
     try:
-        util = importlib.import_module("util.util")
+        importlib.import_module("util.util")
         _set("util.util", "save_network", _save_network_rank0)
     except ImportError:                                   # pragma: no cover - the reference's util needs cv2 (may be absent)
         pass

@@ -62,6 +62,8 @@ class SPADEBGenerator(BaseNetwork):
 
     def forward(self, input=None, z=None, orient_mask=None, image_ref=None, input_tag=None, noise=None,
                 image_tag=None):
+        if torch.is_grad_enabled():
+            ops.expire_fold_expectations()
         spectral.prepare(self)            # every spectral-normed conv of this pass: power iteration + W / sigma + GEMM images, batched
         opt, dt = self.opt, self.compute_dtype
         input_tag = input_tag.float()

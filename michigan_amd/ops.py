@@ -362,6 +362,14 @@ def _grad_premasked(dh: torch.Tensor, h: torch.Tensor, act: int) -> bool:
     return hit
 
 
+def expire_fold_expectations():
+    """A new generator forward in grad mode starts a new graph: expectations a previous forward left without ever running its backward
+    (validation / visualisation passes outside no_grad, under an optimiser that never calls reset_mask_protocol: the drop-in's
+    torch.optim.Adam) must not meet a recycled address later.  Only the error CHECK is keyed on them; the hand-off itself
+    (_RELU_MASKED) is untouched."""
+    _FOLD_EXPECTED.clear()
+
+
 def reset_mask_protocol():
     """Forget every pending mask hand-off (records of a backward pass that was interrupted, forward passes that never got a backward)."""
     _RELU_MASKED.clear()
