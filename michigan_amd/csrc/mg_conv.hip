@@ -588,7 +588,7 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 1 && (value == 0 || value == 1)) { g_mg_conv_bigtiles = value; return MG_OK; }
     if (key == 2 && (value == 0 || value == 1)) { g_mg_conv_halo = value; return MG_OK; }
     if (key == 3 && (value == 0 || value == 1)) { g_mg_wgrad3x3 = value; return MG_OK; }
-    if (key == 4 && value >= 0 && value <= 2) { g_mg_conv_halo_big = value; return MG_OK; }     // 2: bf16 as 1, fp32 stays on the 64-accumulator tile
+    if (key == 4 && (value == 0 || value == 1)) { g_mg_conv_halo_big = value; return MG_OK; }
     if (key == 5 && (value == 0 || value == 1)) { g_mg_conv_splitk = value; return MG_OK; }
     if (key == 17 && (value == 0 || value == 1)) { g_mg_conv_splitk_wide = value; return MG_OK; }
     if (key == 6 && value >= 0 && value <= 2) { g_mg_conv_thin = value; return MG_OK; }

@@ -229,60 +229,18 @@ __global__ __launch_bounds__(NTHR, (NT == 4 || sizeof(T) == 4 ? 2 : 3)) void con
             if constexpr (MT == 2 && NT == 4) __builtin_amdgcn_iglp_opt(1);
 #endif
         } else {
-            if constexpr (NT == 4) {
-                // 128-accumulator tile (round 5): the two-level sums of mma_f32_chunk with ONE temporary tile and the B fragments of one
-                // column tile at a time -- 16 (A) + 8 (B) + 16 (temporary) registers beside the accumulators instead of 48 + 32, which is
-                // what had kept fp32 on the 64-accumulator geometry (mma_f32_chunk's two temporaries + all fragments: 90 spilled
-                // registers here; this form: the three patch pointers, touched once per chunk).  Dependent issues on one temporary are
-                // free: v_mfma_f32_32x32x2_f32 issues every 64 cycles and its dependent latency is 64.  Same blocks, same order of
-                // blocks: bitwise the results of mma_f32_chunk.
-                f32x4_t a[MT][2];
+            f32x4_t a[MT][2], b[NT][2];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    a[mt][0] = *reinterpret_cast<const f32x4_t*>(As + mt * 32 * ROWB + aoff);
-                    a[mt][1] = *reinterpret_cast<const f32x4_t*>(As + mt * 32 * ROWB + (aoff ^ KX));
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(smem + boff[t][nt]);
-                    const f32x4_t b1 = *reinterpret_cast<const f32x4_t*>(smem + (boff[t][nt] ^ KX));
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-#if MG_F32_ONE_CHAIN
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j >> 2][j & 3], (j >> 2) ? b1[j & 3] : b0[j & 3], acc[mt][nt], 0, 0, 0);
-#else
-                        f32x16_t blk;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            f32x16_t c;
-                            if (j == 0) {
-#pragma unroll
-                                for (int e = 0; e < 16; ++e) c[e] = 0.f;
-                            } else
-                                c = blk;
-                            blk = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j >> 2][j & 3], (j >> 2) ? b1[j & 3] : b0[j & 3], c, 0, 0, 0);
-                        }
-                        acc[mt][nt] += blk;
-                        asm volatile("" : "+v"(acc[mt][nt]));         // the add stays here (see mma_f32_chunk)
-#endif
-                    }
-                }
-            } else {
-                f32x4_t a[MT][2], b[NT][2];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    a[mt][0] = *reinterpret_cast<const f32x4_t*>(As + mt * 32 * ROWB + aoff);
-                    a[mt][1] = *reinterpret_cast<const f32x4_t*>(As + mt * 32 * ROWB + (aoff ^ KX));
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    b[nt][0] = *reinterpret_cast<const f32x4_t*>(smem + boff[t][nt]);
-                    b[nt][1] = *reinterpret_cast<const f32x4_t*>(smem + (boff[t][nt] ^ KX));
-                }
-                mma_f32_chunk<MT, NT>(a, b, acc);              // two-level sums: mg_conv_common.h
+            for (int mt = 0; mt < MT; ++mt) {
+                a[mt][0] = *reinterpret_cast<const f32x4_t*>(As + mt * 32 * ROWB + aoff);
+                a[mt][1] = *reinterpret_cast<const f32x4_t*>(As + mt * 32 * ROWB + (aoff ^ KX));
             }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                b[nt][0] = *reinterpret_cast<const f32x4_t*>(smem + boff[t][nt]);
+                b[nt][1] = *reinterpret_cast<const f32x4_t*>(smem + (boff[t][nt] ^ KX));
+            }
+            mma_f32_chunk<MT, NT>(a, b, acc);              // two-level sums: mg_conv_common.h
         }
     };
 
@@ -450,14 +408,12 @@ template <typename T, int EPI>
 int launch_halo(ConvK& k, hipStream_t st)
 {
     if (k.Cout_gemm <= 64) return launch_halo_g<T, EPI, 1, 2>(k, st);
+    // fp32 (the parity configuration): always the 64-accumulator geometry -- the two-level sums of mma_f32_chunk keep 64 more registers
+    // of temporaries in flight, which the 128-accumulator tile has no room for at two workgroups per CU
+    if constexpr (sizeof(T) == 4) return launch_halo_g<T, EPI, 2, 2>(k, st);   // (128-accumulator tile + ONE temporary: 90 spills, 99.8 vs 104.8 images/s on configs[1])
+    else {
     // 16x16-pixel tiles once they still give every CU its two workgroups at least twice over
     const long big = (long)k.N * ((k.Hin + 15) / 16) * ((k.Win + 15) / 16) * ((k.Cout_gemm + 127) / 128);
-    // fp32 (the parity configuration): the 128-accumulator geometry since round 5 (one temporary tile, fragments per column tile: see the
-    // kernel's NT == 4 branch); mg_set_option(4, 2) keeps fp32 on the 64-accumulator tile of round 4 for the A/B
-    if constexpr (sizeof(T) == 4) {
-        if (g_mg_conv_halo_big == 1 && k.Hin >= 16 && big >= 1024) return launch_halo_g<T, EPI, 2, 4>(k, st);
-        return launch_halo_g<T, EPI, 2, 2>(k, st);
-    } else {
     if (g_mg_conv_halo_big && k.Hin >= 16 && big >= 1024) {
 #if MG_PROBES
         if constexpr (sizeof(T) == 2) {
