@@ -95,63 +95,6 @@ __device__ __forceinline__ void mma_f32_chunk(const f32x4_t (&a)[MT][2], const f
     }
 }
 
-// The same two-level sums with the block-sum adds SOFTWARE-PIPELINED across tile groups and across calls (round 5).  In mma_f32_chunk the
-// add of a group's temporaries follows that group's last MFMA in program order: the VALU read of an MFMA result waits for the instruction to
-// finish (64 cycles for v_mfma_f32_32x32x2_f32) and an in-order wave issues nothing meanwhile -- one such bubble per 16 MFMAs = the 6 - 7 %
-// that the two-level sums cost configs[1] in round 4 (111.7 -> 104.3 images/s).  Here a group's temporaries are added only AFTER the next
-// group's 16 MFMAs have been issued (>= 1024 cycles later); the last group of a call stays pending in `pend` and is added behind the first
-// group of the next call (the caller flushes it once after its K loop with mma_f32_flush).  Same blocks, same order per accumulator:
-// bitwise the results of mma_f32_chunk.  `pend` must start as zeros (acc + 0 == acc exactly).
-template <int MT, int NT>
-__device__ __forceinline__ void mma_f32_chunk_pipelined(const f32x4_t (&a)[MT][2], const f32x4_t (&b)[NT][2], f32x16_t (&acc)[MT][NT],
-                                                        f32x16_t (&pend)[2])
-{
-    constexpr int TILES = MT * NT, GT = 2;
-    static_assert(TILES % GT == 0 && TILES >= GT, "tile groups of two");
-    f32x16_t prev[GT] = {pend[0], pend[1]};
-#pragma unroll
-    for (int g0 = 0; g0 < TILES; g0 += GT) {
-        f32x16_t t[GT];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int g = 0; g < GT; ++g) {
-                const int mt = (g0 + g) / NT, nt = (g0 + g) % NT;
-                f32x16_t c;
-                if (j == 0) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) c[e] = 0.f;
-                } else {
-                    c = t[g];
-                }
-                t[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j >> 2][j & 3], b[nt][j >> 2][j & 3], c, 0, 0, 0);
-            }
-        // the PREVIOUS group's block sums (the previous call's last group when g0 == 0): their MFMAs finished long ago
-#pragma unroll
-        for (int g = 0; g < GT; ++g) {
-            const int tile = (g0 == 0 ? TILES : g0) - GT + g;
-            const int mt = tile / NT, nt = tile % NT;
-            acc[mt][nt] += prev[g];
-            asm volatile("" : "+v"(acc[mt][nt]));            // pinned here: behind this group's MFMAs, ahead of the next group's
-        }
-#pragma unroll
-        for (int g = 0; g < GT; ++g) prev[g] = t[g];
-    }
-    pend[0] = prev[0];
-    pend[1] = prev[1];
-}
-
-template <int MT, int NT>
-__device__ __forceinline__ void mma_f32_flush(f32x16_t (&acc)[MT][NT], const f32x16_t (&pend)[2])
-{
-    constexpr int TILES = MT * NT;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int tile = TILES - 2 + g;
-        acc[tile / NT][tile % NT] += pend[g];
-    }
-}
-
 template <typename T, int MT, int NT>
 __device__ __forceinline__ void conv_compute(const unsigned char* As, const unsigned char* Bs, int l31, int hi,
                                              f32x16_t (&acc)[MT][NT])
