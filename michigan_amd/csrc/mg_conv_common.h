@@ -52,9 +52,6 @@ __device__ __forceinline__ int lds_off(int row, int piece) { return row * ROWB +
 // chunk's 8 issues start from ZERO in a temporary tile and the finished 16-term block sum is added to the layer accumulator once:
 // blocks of 16, then a chain of K / 16 block sums -- 1.7e-7 ... 4.4e-7, a CPU kernel's error to within 1.4x.  GT = 2 temporaries in flight keep
 // dependent issues GT MFMAs apart; 16 v_add_f32 per tile and chunk ride in the shadow of 8 x 64 MFMA cycles.
-#ifndef MG_F32_PACKED_ADDS
-#define MG_F32_PACKED_ADDS 0   // 1: the block-sum adds as v_pk_add_f32 (round 4)
-#endif
 template <int MT, int NT>
 __device__ __forceinline__ void mma_f32_chunk(const f32x4_t (&a)[MT][2], const f32x4_t (&b)[NT][2], f32x16_t (&acc)[MT][NT])
 {
@@ -90,21 +87,10 @@ __device__ __forceinline__ void mma_f32_chunk(const f32x4_t (&a)[MT][2], const f
 #pragma unroll
         for (int g = 0; g < GT; ++g) {
             const int mt = (g0 + g) / NT, nt = (g0 + g) % NT;
-#if MG_F32_PACKED_ADDS
             acc[mt][nt] += t[g];
             // pin the add HERE: nothing needs the layer accumulator before the epilogue, so the compiler otherwise sinks every chunk's
             // adds down there and keeps all the block sums alive until then (9 taps x 64 registers of them: 750 spills)
             asm volatile("" : "+v"(acc[mt][nt]));
-#else
-            // ... as 16 scalar v_add_f32, each pinned (which also keeps the SLP vectoriser from re-packing them): beside an MFMA stream a
-            // v_pk_add_f32 costs ~13 cycles more than the two scalar adds it replaces (MI355X_MICROARCH.md, price of a filler)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[mt][nt][e] + t[g][e];
-                asm volatile("" : "+v"(v));
-                acc[mt][nt][e] = v;
-            }
-#endif
         }
     }
 }
