@@ -110,31 +110,11 @@ class SPADEBGenerator(BaseNetwork):
             if cacheable:
                 self.__dict__["_mg_input_cache"] = (key, tuple(weakref.ref(t) for t in src if t is not None), pyramid, hair_masks)
 
-        # The background encoder (7x7 + three 4x4 / stride-2 convs on the target image) is an input-only branch whose features are first needed
-        # by up_0's blend: on the side stream it runs beside head_0 / G_middle_* -- 8x8 ... 32x32 blocks whose launches cannot fill 256 CUs --
-        # and autograd runs its backward there too, beside the main chain's.  (ops.BG_SIDE_STREAM; MG_BG_STREAM=0: inline.)
-        bg_ev = None
-        if ops.BG_SIDE_STREAM and ops.WGRAD_SIDE_STREAM and x.is_cuda:
-            main, side = torch.cuda.current_stream(x.device), ops.side_stream(x.device)
-            side.wait_stream(main)                               # inputs and this step's packed weights come from the main stream
-            with torch.cuda.stream(side):
-                back_feats, back_masks = self.backgroud_enc(image_tag, input_tag, noise)
-                bg_ev = torch.cuda.Event()
-                bg_ev.record(side)
-        else:
-            back_feats, back_masks = self.backgroud_enc(image_tag, input_tag, noise)
+        back_feats, back_masks = self.backgroud_enc(image_tag, input_tag, noise)
 
         x = self.head_0(x, pyramid)
         x = self.G_middle_0(x, pyramid, up=True)
         x = self.G_middle_1(x, pyramid, up=opt.num_upsampling_layers == "more")
-        if bg_ev is not None:
-            main.wait_event(bg_ev)
-            for t in list(back_feats) + list(back_masks):
-                if torch.is_tensor(t):
-                    t.record_stream(main)                        # allocated on the side stream, consumed here
-            for t in (image_tag, input_tag, noise):
-                if torch.is_tensor(t):
-                    t.record_stream(side)
         for i, block in enumerate((self.up_0, self.up_1, self.up_2, self.up_3)):
             x = block(x, pyramid, up=True)            # the 2x nearest upsample is folded into the block's first SPADE layers
             last = i == 3

@@ -537,14 +537,6 @@ def sink_wgrad(arena, slot, x, dy, kh, kw, stride, pad, need_b):
     arena.slot_written(slot[0])
 
 
-BG_SIDE_STREAM = os.environ.get("MG_BG_STREAM", "1") != "0"     # the generator's background encoder on the side stream (networks/generator.py)
-
-
-def side_stream(device):
-    """The lowest-priority stream for leaf / input-only work (shared with the weight gradients)."""
-    return _wgrad_side(device)[0]
-
-
 def _wgrad_swapped(stride: int, cg8: int, cin: int) -> bool:
     return stride == 1 and cg8 <= 8 and cin >= 32
 
