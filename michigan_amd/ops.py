@@ -465,7 +465,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int,
 # A weight gradient is a LEAF of the backward pass: nothing reads it before the optimiser's gradient drain.  The data-gradient chain it
 # hangs off alternates MFMA-bound convolutions with HBM-bound passes (SPADE's reduce / apply, activation and pooling adjoints: ~7 ms of
 # a 65 ms step) during which the matrix pipes idle, and every launch of the chain ends in a tail of half-empty CUs.  The gradient
-# sink's wgrad launches therefore go to a second, lowest-priority stream: ordered behind the producer of dy by an event, joined by the
+# sink's wgrad launches therefore go to a second stream: ordered behind the producer of dy by an event, joined by the
 # main stream before anything reads or re-zeroes the GEMM-order arena (FlatAdam.drain_grads / sync_grads / zero_grad), their operands
 # kept alive by record_stream.  Same kernels, same atomics: results are those of the in-stream order up to atomic order.
 # Measured (round 5, bs 8 / 512^2 / bf16, A B A B in one process, profiles/r05_side_stream_ab.txt): 65.1 -> 63.6 ms per step (-2.2 %),
@@ -476,22 +476,11 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int,
 # at the top of the generator pass (+0.4 ms).  MG_WGRAD_STREAM=0 restores the single stream.
 WGRAD_SIDE_STREAM = os.environ.get("MG_WGRAD_STREAM", "1") != "0"
 _WGRAD_STREAMS = {}            # device index -> [stream, dirty, held]: held = [(event, x, dy)] of launches that may still be running
-WGRAD_STREAM_PRIORITY = os.environ.get("MG_WGRAD_STREAM_PRIO", "low")      # "low": the least HIP stream priority of the device; "normal": torch's default
-
-
 def _new_side_stream(device):
-    """A stream for leaf work that must never delay the critical path: the LOWEST priority the device offers, so that whenever both
-    queues have workgroups to place the dispatcher serves the main stream first (torch.cuda.Stream only exposes normal / high)."""
-    if WGRAD_STREAM_PRIORITY == "low":
-        try:
-            hip = ctypes.CDLL("libamdhip64.so")
-            least, greatest, st = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_void_p()
-            with torch.cuda.device(device):
-                if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) == 0 and least.value != greatest.value \
-                        and hip.hipStreamCreateWithPriority(ctypes.byref(st), ctypes.c_uint(1), ctypes.c_int(least.value)) == 0 and st.value:
-                    return torch.cuda.ExternalStream(st.value, device=device)         # lives as long as the process
-        except (OSError, AttributeError):
-            pass
+    """The side stream is an ordinary stream at torch's default priority.  One created at the device's LOWEST priority
+    (hipStreamCreateWithPriority) measured the same single-GPU gain (65.1 -> 63.6 vs 64.6 -> 63.3 ms) but cost 16 ms per step as soon as the
+    step contained RCCL collectives (one rank, every collective forced: 83.5 ms against 65.6 with this stream and 67.1 with no side stream
+    at all, whichever stream the collectives were issued on: profiles/r05_side_stream_ab.txt) -- removed."""
     return torch.cuda.Stream(device=device)
 
 

@@ -826,9 +826,10 @@ def test_side_stream_weight_gradient_survives_inplace_gradient_accumulation():
             if side:
                 with torch.cuda.stream(ops._wgrad_side(x.device)[0]):
                     torch.cuda._sleep(40_000_000)                # ~20 ms: every side-stream launch of this backward starts late
-            y = conv(h, resid=h)                                  # dy of the conv == gradient of `resid`, arrives first ...
-            z = y + h * 3.0                                       # ... then the second gradient for h is added to it
-            z.backward(gy)
+            u = h * 2.0
+            y = conv(u, resid=h)                                  # the conv's backward hands ONLY dres (== its dy) to h: the first gradient
+            z = y * 1.0                                           #   to arrive there, engine-owned (the conv's dy is no user tensor) ...
+            z.backward(gy)                                        # ... and `u = 2 h`'s backward then adds 2 du INTO it, in place
             optim.finalize_grads()
             torch.cuda.synchronize()
             res.setdefault(side, []).append((conv.weight.grad.detach().float().clone(), x.grad.detach().float().clone()))

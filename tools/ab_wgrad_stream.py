@@ -1,5 +1,5 @@
 """Weight gradients on a side stream (ops.WGRAD_SIDE_STREAM, MG_WGRAD_STREAM=1) against the in-stream order on the benchmarked step
-(bs 8, 512^2, bf16), A B A B in one process; MG_WGRAD_STREAM_PRIO=low|normal picks the side stream's priority.   (GPU box)"""
+(bs 8, 512^2, bf16), A B A B in one process.   (GPU box)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("HSA_KERNARG_POOL_SIZE", str(64 << 20))
@@ -15,7 +15,7 @@ data = {k: v.cuda() for k, v in synth_batch(bs, 512, seed=1234).items()}
 def step():
     tr.run_generator_one_step(data); tr.run_discriminator_one_step(data)
 for _ in range(3): step()
-print(f"# bs {bs}, side-stream priority {ops.WGRAD_STREAM_PRIORITY}")
+print(f"# bs {bs}")
 for rep in range(4):
     for v in (False, True):
         ops.WGRAD_SIDE_STREAM = v
