@@ -122,7 +122,8 @@ typedef struct mg_wgrad_desc {
     int32_t isy, isx;
     int32_t ntaps;
     int32_t splitk;        /* 0 = choose automatically                        */
-    int32_t flags;         /* bit0: bf16 operands via ds_read_b64_tr_b16      */
+    int32_t flags;         /* bit0: bf16 operands via ds_read_b64_tr_b16; bit1: this launch runs beside another stream's kernels -- the
+                              kernel-row 3x3 kernel then keeps to ONE workgroup per CU (results unchanged) */
     int8_t  tap_dy[MG_MAX_TAPS];
     int8_t  tap_dx[MG_MAX_TAPS];
     void*   det_ws;        /* optional: deterministic split-K workspace (see below), NULL = fp32 atomics */

@@ -315,7 +315,12 @@ int launch3(Wg3K& k, hipStream_t st, int* nsplit, bool dry)
     if (dry) return MG_OK;
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_wgrad: bad grid %ld", nblk);
     auto kern = wgrad3x3_kernel<MT, NT, W16>;
-    mg_raise_lds_cap(reinterpret_cast<const void*>(kern), (int)LDS);
+    // flags bit 1 (a launch that runs BESIDE another stream's kernels: ops.sink_wgrad): request more than half a CU's LDS, i.e. ONE workgroup of
+    // this kernel per CU -- the other half of every CU (registers, LDS, wave slots) stays with the main stream.  63.9 -> 63.3 ms per step
+    // on top of the side stream itself (profiles/r05_side_stream_ab.txt); in stream order it only halves the kernel's occupancy: off there.
+    constexpr size_t LDS_HALF_CU = LDS > 84 * 1024 ? LDS : 84 * 1024;
+    const size_t lds_req = k.half_cu ? LDS_HALF_CU : LDS;
+    mg_raise_lds_cap(reinterpret_cast<const void*>(kern), (int)LDS_HALF_CU);
 #if MG_PROBES
     if constexpr (MT == 2 && NT == 2 && !W16) {
         if (g_mg_wgrad3x3_probe) {
@@ -327,7 +332,7 @@ int launch3(Wg3K& k, hipStream_t st, int* nsplit, bool dry)
         }
     }
 #endif
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), LDS, st, k);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_req, st, k);
     MG_CHECK_LAUNCH("mg_conv_wgrad(3x3)");
     return MG_OK;
 }
