@@ -31,7 +31,6 @@ struct WgK {
     int tiles_m, tiles_n, splitk;
     int tpt;          // taps packed into one 128-wide N tile (Cin < 128 and 128 % Cin == 0), else 1
     long det_stride;  // deterministic mode: floats per split slab (dw / dbias point into the workspace), 0 = fp32 atomics
-    int half_cu;      // mg_wgrad_desc.flags bit 1: one workgroup of this kernel per CU (the launch runs beside another stream's kernels)
     int tap[MG_MAX_TAPS];
 };
 
@@ -340,11 +339,7 @@ int launch_wgrad(WgK& k, hipStream_t st, int* nsplit = nullptr, bool dry = false
     if (nsplit) *nsplit = S;
     if (dry) return MG_OK;
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_wgrad: bad grid %ld", nblk);
-    size_t lds = 2 * 2 * (size_t)KP * RS;
-    if (k.half_cu) {                                           // see mg_wgrad3x3.hip launch3: > 80 KiB of LDS = one workgroup per CU
-        mg_raise_lds_cap(reinterpret_cast<const void*>(wgrad_kernel<T, TR>), 84 * 1024);
-        lds = lds > 84 * 1024 ? lds : 84 * 1024;
-    }
+    const size_t lds = 2 * 2 * (size_t)KP * RS;           // (capping THIS kernel at one workgroup per CU beside another stream cost +1.6 ms per step: not done)
     hipLaunchKernelGGL((wgrad_kernel<T, TR>), dim3((unsigned)nblk), dim3(NTHR), lds, st, k);
     MG_CHECK_LAUNCH("mg_conv_wgrad");
     return MG_OK;
@@ -373,7 +368,6 @@ int route_wgrad(const mg_wgrad_desc* d, hipStream_t st, float* dw, float* dbias,
     k.N = d->N; k.Hin = d->Hin; k.Win = d->Win; k.Cin = d->Cin;
     k.Hj = d->Hj; k.Wj = d->Wj; k.Cg = d->Cg; k.isy = d->isy; k.isx = d->isx; k.ntaps = d->ntaps;
     k.K = d->N * d->Hj * d->Wj; k.splitk = d->splitk; k.kper = 0; k.tiles_m = k.tiles_n = 0; k.tpt = 1; k.det_stride = det_stride;
-    k.half_cu = (d->flags & 4) ? 1 : 0;          // (A/B: bit 2 for this kernel, bit 1 for the kernel-row 3x3 kernel)
     for (int t = 0; t < MG_MAX_TAPS; ++t)
         k.tap[t] = t < d->ntaps ? (int)((((uint32_t)(int)d->tap_dy[t]) & 0xffffu) | (((uint32_t)(int)d->tap_dx[t]) << 16)) : 0;
     if (d->dtype == MG_BF16 && d->ntaps == 9 && d->isy == 1 && d->isx == 1 && d->Hin == d->Hj && d->Win == d->Wj && d->Cin == 8) {
