@@ -468,12 +468,13 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int,
 # sink's wgrad launches therefore go to a second stream: ordered behind the producer of dy by an event, joined by the
 # main stream before anything reads or re-zeroes the GEMM-order arena (FlatAdam.drain_grads / sync_grads / zero_grad), their operands
 # kept alive by record_stream.  Same kernels, same atomics: results are those of the in-stream order up to atomic order.
-# Measured (round 5, bs 8 / 512^2 / bf16, A B A B in one process, profiles/r05_side_stream_ab.txt): 65.1 -> 63.6 ms per step (-2.2 %),
-# 39.3 -> 37.6 at bs 4; the kernel trace (profiles/r05_stream_overlap.txt) has two queues busy 29 % of the time.  What did NOT pay on
-# top of it, same A/B: capping the side kernels at one workgroup per CU (LDS request > 80 KiB: 63.8 / 63.3), and moving SPADE's whole
-# conditioning branch (mlp_shared forward, the gamma|beta data gradient and its adjoint) over as well (65.0: the step's critical path
-# then waits for side-stream work it used to run itself), or only its forward half, all 36 mlp_shared convs prefetched on the side stream
-# at the top of the generator pass (+0.4 ms).  MG_WGRAD_STREAM=0 restores the single stream.
+# Measured (round 5, bs 8 / 512^2 / bf16, A B A B in one process, profiles/r05_side_stream_ab.txt): 65.6 -> 63.3 ms per step, 38.7 -> 37.4
+# at bs 4, 67.1 -> 65.5 with one rank and every collective forced over RCCL; the kernel trace (profiles/r05_stream_overlap.txt) has two
+# queues busy 29 % of the time.  On the side stream the kernel-row 3x3 kernel keeps to ONE workgroup per CU (mg_wgrad_desc.flags bit 1:
+# -0.6 / -0.55 / 0.0 ms on three boxes; the generic kernel capped the same way: +1.6 ms, not done).  What did NOT pay, same A/Bs: a
+# lowest-priority side stream (same on one GPU, +16 ms per step beside RCCL collectives), SPADE's whole conditioning branch over there
+# (65.0: the critical path then waits for side-stream work it used to run itself), its forward half prefetched at the top of the generator
+# pass (+0.4 ms), the background encoder beside head_0 / G_middle_* (flat).  MG_WGRAD_STREAM=0 restores the single stream.
 WGRAD_SIDE_STREAM = os.environ.get("MG_WGRAD_STREAM", "1") != "0"
 WGRAD_HALF_CU = os.environ.get("MG_WGRAD_HALF_CU", "1") != "0"     # side-stream wgrad3x3 launches keep to one workgroup per CU (flags bit 1): -0.6 / -0.55 / 0.0 ms on three boxes
 _WGRAD_BESIDE = False
