@@ -467,7 +467,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int,
 # a 65 ms step) during which the matrix pipes idle, and every launch of the chain ends in a tail of half-empty CUs.  The gradient
 # sink's wgrad launches therefore go to a second stream: ordered behind the producer of dy by an event, joined by the
 # main stream before anything reads or re-zeroes the GEMM-order arena (FlatAdam.drain_grads / sync_grads / zero_grad), their operands
-# kept alive by record_stream.  Same kernels, same atomics: results are those of the in-stream order up to atomic order.
+# kept referenced until their launch has finished (sink_wgrad).  Same kernels, same atomics: results are those of the in-stream order up to atomic order.
 # Measured (round 5, bs 8 / 512^2 / bf16, A B A B in one process, profiles/r05_side_stream_ab.txt): 65.6 -> 63.3 ms per step, 38.7 -> 37.4
 # at bs 4, 67.1 -> 65.5 with one rank and every collective forced over RCCL; the kernel trace (profiles/r05_stream_overlap.txt) has two
 # queues busy 29 % of the time.  On the side stream the kernel-row 3x3 kernel keeps to ONE workgroup per CU (mg_wgrad_desc.flags bit 1:
