@@ -479,6 +479,8 @@ WGRAD_SIDE_STREAM = os.environ.get("MG_WGRAD_STREAM", "1") != "0"
 WGRAD_HALF_CU = os.environ.get("MG_WGRAD_HALF_CU", "1") != "0"     # side-stream wgrad3x3 launches keep to one workgroup per CU (flags bit 1): -0.6 / -0.55 / 0.0 ms on three boxes
 _WGRAD_BESIDE = False
 _WGRAD_STREAMS = {}            # device index -> [stream, dirty, held]: held = [(event, x, dy)] of launches that may still be running
+
+
 def _new_side_stream(device):
     """The side stream is an ordinary stream at torch's default priority.  One created at the device's LOWEST priority
     (hipStreamCreateWithPriority) measured the same single-GPU gain (65.1 -> 63.6 vs 64.6 -> 63.3 ms) but cost 16 ms per step as soon as the
