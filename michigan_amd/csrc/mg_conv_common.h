@@ -95,66 +95,6 @@ __device__ __forceinline__ void mma_f32_chunk(const f32x4_t (&a)[MT][2], const f
     }
 }
 
-// The same two-level sums with the block-sum adds INTERLEAVED with the next tile group's MFMAs (round 5).  mma_f32_chunk adds a group's two
-// temporaries (32 v_add_f32) in one clump behind the group's 16 MFMAs: the wave issues ~100 cycles of VALU during which it issues no MFMA, and
-// the matrix pipe (one 64-cycle v_mfma_f32_32x32x2_f32 in flight per wave) runs dry for the rest of the clump -- the 6 - 7 % that the two-level
-// sums cost configs[1].  Here the previous group's block sums (kept in `pend` across calls; zeros at the start, flushed by the caller with
-// mma_f32_flush) are added two elements at a time right behind each MFMA of the current group, so that every MFMA issue is followed by a gap's
-// worth of VALU and the next MFMA.  Same blocks, same order per accumulator: bitwise the results of mma_f32_chunk.
-template <int MT, int NT>
-__device__ __forceinline__ void mma_f32_chunk_interleaved(const f32x4_t (&a)[MT][2], const f32x4_t (&b)[NT][2], f32x16_t (&acc)[MT][NT],
-                                                          f32x16_t (&pend)[2])
-{
-    constexpr int TILES = MT * NT, GT = 2;
-    static_assert(TILES % GT == 0 && TILES >= GT, "tile groups of two");
-    f32x16_t prev[GT] = {pend[0], pend[1]};
-#pragma unroll
-    for (int g0 = 0; g0 < TILES; g0 += GT) {
-        f32x16_t t[GT];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int g = 0; g < GT; ++g) {
-                const int mt = (g0 + g) / NT, nt = (g0 + g) % NT;
-                f32x16_t c;
-                if (j == 0) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) c[e] = 0.f;
-                } else {
-                    c = t[g];
-                }
-                t[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j >> 2][j & 3], b[nt][j >> 2][j & 3], c, 0, 0, 0);
-                // two elements of the PREVIOUS group's block sums behind this MFMA (16 MFMAs x 2 = the group's 32 elements)
-                const int i2 = (j * GT + g) * 2;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int pe = i2 + q, pg = pe / 16, el = pe % 16;
-                    const int tile = (g0 == 0 ? TILES : g0) - GT + pg;
-                    float v = acc[tile / NT][tile % NT][el] + prev[pg][el];
-                    asm volatile("" : "+v"(v));
-                    acc[tile / NT][tile % NT][el] = v;
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA ...
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // ... then two VALU
-            }
-#pragma unroll
-        for (int g = 0; g < GT; ++g) prev[g] = t[g];
-    }
-    pend[0] = prev[0];
-    pend[1] = prev[1];
-}
-
-template <int MT, int NT>
-__device__ __forceinline__ void mma_f32_flush(f32x16_t (&acc)[MT][NT], const f32x16_t (&pend)[2])
-{
-    constexpr int TILES = MT * NT;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int tile = TILES - 2 + g;
-        acc[tile / NT][tile % NT] += pend[g];
-    }
-}
-
 template <typename T, int MT, int NT>
 __device__ __forceinline__ void conv_compute(const unsigned char* As, const unsigned char* Bs, int l31, int hi,
                                              f32x16_t (&acc)[MT][NT])

@@ -183,13 +183,6 @@ __global__ __launch_bounds__(NTHR, (NT == 4 || sizeof(T) == 4 ? 2 : 3)) void con
         }
     }
 
-    f32x16_t pend32[2];                                          // fp32: block sums of the last tile group, added behind the next tap's first MFMAs
-    if constexpr (!BF) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) pend32[g][r] = 0.f;
-    }
     auto compute = [&](auto t_, int slot, auto first_) {
         constexpr int t = decltype(t_)::value;
         constexpr bool FIRST = decltype(first_)::value;          // very first K step of the workgroup: C = 0
@@ -247,11 +240,7 @@ __global__ __launch_bounds__(NTHR, (NT == 4 || sizeof(T) == 4 ? 2 : 3)) void con
                 b[nt][0] = *reinterpret_cast<const f32x4_t*>(smem + boff[t][nt]);
                 b[nt][1] = *reinterpret_cast<const f32x4_t*>(smem + (boff[t][nt] ^ KX));
             }
-#if MG_F32_ONE_CHAIN
-            mma_f32_chunk<MT, NT>(a, b, acc);
-#else
-            mma_f32_chunk_interleaved<MT, NT>(a, b, acc, pend32);     // two-level sums, the adds spread between the next group's MFMAs: mg_conv_common.h
-#endif
+            mma_f32_chunk<MT, NT>(a, b, acc);              // two-level sums: mg_conv_common.h
         }
     };
 
@@ -371,9 +360,6 @@ __global__ __launch_bounds__(NTHR, (NT == 4 || sizeof(T) == 4 ? 2 : 3)) void con
         for (int c = 1; c < nchunk; ++c) chunk(c, std::false_type{});
     }
 
-#if !MG_F32_ONE_CHAIN
-    if constexpr (!BF) mma_f32_flush<MT, NT>(acc, pend32);
-#endif
 #if MG_PROBES
     if (PROBE != 4 && (d.wide & 2)) {                            // measurement aid (mg_set_option(10, 1)): main loop only; one store keeps the MFMAs alive
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<T*>(d.out)[0] = (T)1;
