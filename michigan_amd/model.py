@@ -240,14 +240,32 @@ class Pix2PixModel(nn.Module):
         d = self._maybe_inpaint(d)
         pending = self._ref_is_tag_async(d)
         fake = self.generate_fake(d)
-        pred_fake, pred_real = self.discriminate(d, fake, split=True)
         label = d["input_tag"][:, 1:2]
-        if not self.opt.no_gan_loss:
-            losses["GAN"] = self.criterionGAN(pred_fake, True, for_discriminator=False, label=label)
-        ref_is_tag = self._resolve_flag(pending)
-        if self.opt.curr_step == 1 and ref_is_tag:
-            if not self.opt.no_ganFeat_loss:
+        from . import ops
+        branch = ops.BRANCH_STREAMS and ops.WGRAD_SIDE_STREAM and fake.is_cuda
+        if branch:
+            # The discriminator branch (D on fake / real, GAN + feature-matching losses) and the VGG / orientation branch both hang off `fake`
+            # and are independent until their gradients meet there: the D branch is issued to the side stream -- its launches are small
+            # (4x4 convs on 33^2 ... 257^2 maps) -- beside the VGG tower on the main stream; autograd runs each node's backward on the stream
+            # its forward ran on and orders the accumulation at `fake`.
+            main, side = torch.cuda.current_stream(fake.device), ops.side_stream(fake.device)
+            side.wait_stream(main)
+            fake.record_stream(side)
+            ref_is_tag = self._resolve_flag(pending)
+            with torch.cuda.stream(side):
+                pred_fake, pred_real = self.discriminate(d, fake, split=True)
+                if not self.opt.no_gan_loss:
+                    losses["GAN"] = self.criterionGAN(pred_fake, True, for_discriminator=False, label=label)
+                if self.opt.curr_step == 1 and ref_is_tag and not self.opt.no_ganFeat_loss:
+                    losses["GAN_Feat"] = self.criterionGANFeat(pred_fake, pred_real, label)
+        else:
+            pred_fake, pred_real = self.discriminate(d, fake, split=True)
+            if not self.opt.no_gan_loss:
+                losses["GAN"] = self.criterionGAN(pred_fake, True, for_discriminator=False, label=label)
+            ref_is_tag = self._resolve_flag(pending)
+            if self.opt.curr_step == 1 and ref_is_tag and not self.opt.no_ganFeat_loss:
                 losses["GAN_Feat"] = self.criterionGANFeat(pred_fake, pred_real, label)
+        if self.opt.curr_step == 1 and ref_is_tag:
             if not self.opt.no_vgg_loss:
                 losses["VGG"] = _scaled(self.criterionVGG(fake, d["image_tag"], label), self.opt.lambda_vgg)
         if not getattr(self.opt, "no_orient_loss", True):
@@ -255,6 +273,11 @@ class Pix2PixModel(nn.Module):
             losses["ORIENT"] = _scaled(orient, self.opt.lambda_orient)
             if not self.opt.no_confidence_loss:
                 losses["CONFIDENCE"] = conf * self.opt.lambda_confidence
+        if branch:
+            main.wait_stream(side)                                # the D branch's loss scalars are summed on the main stream
+            for k in ("GAN", "GAN_Feat"):
+                if k in losses and torch.is_tensor(losses[k]):
+                    losses[k].record_stream(main)
         return losses, fake
 
     def compute_discriminator_loss(self, d):

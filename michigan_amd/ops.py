@@ -536,6 +536,14 @@ def sink_wgrad(arena, slot, x, dy, kh, kw, stride, pad, need_b):
     arena.slot_written(slot[0])
 
 
+BRANCH_STREAMS = os.environ.get("MG_BRANCH_STREAMS", "0") == "1"     # generator step: the discriminator branch on the side stream beside the VGG branch (model.py)
+
+
+def side_stream(device):
+    """The second stream of the step (shared with the weight gradients)."""
+    return _wgrad_side(device)[0]
+
+
 def _wgrad_swapped(stride: int, cg8: int, cin: int) -> bool:
     return stride == 1 and cg8 <= 8 and cin >= 32
 
