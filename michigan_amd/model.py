@@ -239,19 +239,30 @@ class Pix2PixModel(nn.Module):
         losses = {}
         d = self._maybe_inpaint(d)
         pending = self._ref_is_tag_async(d)
-        fake = self.generate_fake(d)
-        label = d["input_tag"][:, 1:2]
         from . import ops
-        branch = ops.BRANCH_STREAMS and ops.WGRAD_SIDE_STREAM and fake.is_cuda
+        label = d["input_tag"][:, 1:2]
+        branch = ops.BRANCH_STREAMS and ops.WGRAD_SIDE_STREAM and d["image_tag"].is_cuda
+        y_feats = None
+        if branch:
+            # (the host has to wait for this flag once per step anyway: it is far ahead of the GPU when it gets here)
+            ref_is_tag = self._resolve_flag(pending)
+            main, side = torch.cuda.current_stream(d["image_tag"].device), ops.side_stream(d["image_tag"].device)
+            if int(ops.BRANCH_STREAMS) >= 2 and self.opt.curr_step == 1 and ref_is_tag and not self.opt.no_vgg_loss:
+                # the real image's VGG features depend on the batch alone: on the side stream beside the generator pass
+                side.wait_stream(main)
+                with torch.cuda.stream(side), torch.no_grad():
+                    y_feats = self.criterionVGG.vgg(d["image_tag"])
+                    y_ev = torch.cuda.Event()
+                    y_ev.record(side)
+                d["image_tag"].record_stream(side)
+        fake = self.generate_fake(d)
         if branch:
             # The discriminator branch (D on fake / real, GAN + feature-matching losses) and the VGG / orientation branch both hang off `fake`
             # and are independent until their gradients meet there: the D branch is issued to the side stream -- its launches are small
             # (4x4 convs on 33^2 ... 257^2 maps) -- beside the VGG tower on the main stream; autograd runs each node's backward on the stream
             # its forward ran on and orders the accumulation at `fake`.
-            main, side = torch.cuda.current_stream(fake.device), ops.side_stream(fake.device)
             side.wait_stream(main)
             fake.record_stream(side)
-            ref_is_tag = self._resolve_flag(pending)
             with torch.cuda.stream(side):
                 pred_fake, pred_real = self.discriminate(d, fake, split=True)
                 if not self.opt.no_gan_loss:
@@ -267,7 +278,11 @@ class Pix2PixModel(nn.Module):
                 losses["GAN_Feat"] = self.criterionGANFeat(pred_fake, pred_real, label)
         if self.opt.curr_step == 1 and ref_is_tag:
             if not self.opt.no_vgg_loss:
-                losses["VGG"] = _scaled(self.criterionVGG(fake, d["image_tag"], label), self.opt.lambda_vgg)
+                if y_feats is not None:
+                    main.wait_event(y_ev)
+                    for t in y_feats:
+                        t.record_stream(main)
+                losses["VGG"] = _scaled(self.criterionVGG(fake, d["image_tag"], label, y_feats=y_feats), self.opt.lambda_vgg)
         if not getattr(self.opt, "no_orient_loss", True):
             orient, conf = self.criterionOrient(fake, d["orient"], d["input_tag"])
             losses["ORIENT"] = _scaled(orient, self.opt.lambda_orient)

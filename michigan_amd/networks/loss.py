@@ -158,9 +158,11 @@ class VGGLoss(nn.Module):
         lab = F.interpolate(label, size=input.shape[2:], mode="nearest")
         return F.l1_loss(input * lab, target * lab, reduction="sum") / (lab.sum() * input.shape[1] + 1e-5)
 
-    def forward(self, x, y, label=None):
-        with torch.no_grad():
-            y_feats = self.vgg(y)
+    def forward(self, x, y, label=None, y_feats=None):
+        """`y_feats`: the (detached) tower features of y when the caller already has them (model.py computes them on the side stream)."""
+        if y_feats is None:
+            with torch.no_grad():
+                y_feats = self.vgg(y)
         x_feats = self.vgg(x)
         vals = []
         for a, b in zip(x_feats, y_feats):

@@ -536,7 +536,7 @@ def sink_wgrad(arena, slot, x, dy, kh, kw, stride, pad, need_b):
     arena.slot_written(slot[0])
 
 
-BRANCH_STREAMS = os.environ.get("MG_BRANCH_STREAMS", "0") == "1"     # generator step: the discriminator branch on the side stream beside the VGG branch (model.py)
+BRANCH_STREAMS = int(os.environ.get("MG_BRANCH_STREAMS", "0"))      # generator step: 1 = the discriminator branch on the side stream beside the VGG branch; 2 = + VGG(real image) beside the generator pass (model.py)
 
 
 def side_stream(device):
