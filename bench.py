@@ -393,7 +393,7 @@ def main():
                                     f"{a.size}x{a.size}, BASELINE.json configs[1]"),
                        "global_batch": gbatch, "batch_per_gpu": a.batch_per_gpu, "resolution": a.size,
                        "parallelism": f"dp{world}", "init": "reference default (xavier, 0.02), random VGG weights",
-                       "streams": ("weight gradients on a side stream (ops.sink_wgrad); roofline launch timings from one extra single-stream step"
+                       "streams": ("second stream: weight gradients (ops.sink_wgrad), the generator step's discriminator branch and VGG(real) (ops.BRANCH_STREAMS); roofline launch timings from one extra single-stream step"
                                    if _streams_on() else "single stream (MG_WGRAD_STREAM=0)")},
             "step_tflops_effective": {"vs_reference_work": round(value * step_gflop_ref / 1e3 / world, 1),
                                       "vs_minimum_work": round(value * step_gflop_min / 1e3 / world, 1),

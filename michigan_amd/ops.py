@@ -536,7 +536,13 @@ def sink_wgrad(arena, slot, x, dy, kh, kw, stride, pad, need_b):
     arena.slot_written(slot[0])
 
 
-BRANCH_STREAMS = int(os.environ.get("MG_BRANCH_STREAMS", "0"))      # generator step: 1 = the discriminator branch on the side stream beside the VGG branch; 2 = + VGG(real image) beside the generator pass (model.py)
+# Generator step (model.Pix2PixModel.compute_generator_loss): the losses' branches on two streams.  1 = the discriminator branch (D on fake / real,
+# GAN + feature-matching losses: small 4x4-conv launches) on the side stream beside the VGG / orientation branch; autograd runs each node's backward
+# on its forward's stream, so the two backward branches overlap as well.  2 (default) = also the real image's VGG features (no graph, input-only)
+# on the side stream beside the generator pass.  Measured A B C C B A x 3 in one process (profiles/r05_side_stream_ab.txt): 64.51 / 63.96 / 63.22
+# ms per step for 0 / 1 / 2; a second box 62.86 / 63.09 / 61.92; parity suite green in mode 2.  Needs WGRAD_SIDE_STREAM (MG_WGRAD_STREAM=0 turns
+# every second-stream use off).
+BRANCH_STREAMS = int(os.environ.get("MG_BRANCH_STREAMS", "2"))
 
 
 def side_stream(device):
