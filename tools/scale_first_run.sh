@@ -26,7 +26,7 @@ except Exception as e:
     print(f"{name:28s} N={n}  FAILED ({e}); see {path}.err")
 PY
 }
-echo "# bench.py --batch-per-gpu $BPG --steps $STEPS on $NGPU GPU(s); default = one communicator, in-stream sync-BN, grad buckets on the process group's stream, weight gradients on the side stream"
+echo "# bench.py --batch-per-gpu $BPG --steps $STEPS on $NGPU GPU(s); default = one communicator, in-stream sync-BN, grad buckets on the process group's stream, weight gradients + the generator step's D branch / VGG(real) on the second stream"
 line default 1
 for N in 2 4 8; do
     [ "$N" -le "$NGPU" ] || continue
@@ -34,6 +34,7 @@ for N in 2 4 8; do
     line syncbn_async      $N MG_SYNCBN_ASYNC=1
     line two_groups        $N MG_DP_TWO_GROUPS=1
     line grads_in_stream   $N MG_DP_GRAD_SIDE=0
-    line wgrad_in_stream   $N MG_WGRAD_STREAM=0
+    line single_stream     $N MG_WGRAD_STREAM=0
+    line no_branch_streams $N MG_BRANCH_STREAMS=0
 done
 echo "# scaling efficiency = value(N) / (N x value(1)); the >= 6.5x target of BASELINE.json is value(8) / value(1) at this per-GPU batch"
