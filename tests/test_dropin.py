@@ -243,3 +243,31 @@ def test_checkpoint_round_trip_resumes_exactly(emulator_backend, tmp_path):
         assert abs(x - y) <= (1e-3 if k == "ORIENT" else 1e-5) * max(abs(x), 0.1), k
     for oa, ob in ((a.optimizer_G, b.optimizer_G), (a.optimizer_D, b.optimizer_D)):
         assert ((oa.flat - ob.flat).abs() > 2e-5).float().mean() < 0.01           # 2e-5 = a fifth of one update (lr 1e-4)
+
+
+@needs_reference
+def test_fullwidth_step_protocol_on_the_emulator(emulator_backend):
+    """oracle/fullwidth_step.py (the live reference comparison tests/test_gpu_fullwidth_reference.py runs at ngf 64 / 512x512 on the GPU
+    box) at a width the float64 contract emulator finishes in seconds: the reference child process writes its record, this repo's trainer
+    on the emulator reproduces every loss, the image, the gradient AT the image, all discriminator weight gradients and the recorded
+    generator gradients.  fp32 host stack on float64 kernels vs fp32 ATen: 2e-4 on losses / image, 2e-3 relative L2 on gradients."""
+    from oracle import fullwidth_step as FW
+    from michigan_amd.model import Pix2PixTrainer
+    cfg = FW.CFG_SMALL
+    with tempfile.TemporaryDirectory() as d:
+        ref = FW.reference_record_in_child("small", d)
+        ref = {k: ref[k] for k in ref.files}
+
+    def make():
+        torch.manual_seed(0)
+        return Pix2PixTrainer(TP.repo_options(cfg))
+    rec = FW.run_protocol(make, cfg, finalize=lambda tr, w: (tr.optimizer_G if w == "G" else tr.optimizer_D).finalize_grads())
+    assert not set(rec) ^ set(ref), set(rec) ^ set(ref)
+    assert "g.grad.image" in ref and sum(k.startswith("d.grad.D.") for k in ref) == 14          # 2 scales x (2 + 3 + 2) parameters
+    bad = {}
+    for k, (kind, *v) in FW.distances(rec, ref).items():
+        later = k.startswith("later.")
+        lim = {"loss": 1e-2 if later else 2e-4, "image": 2e-4, "grad": 2e-3, "buffer": 1e-2 if later else 1e-4}[kind]
+        if not v[0] <= lim:
+            bad[k] = (kind, v, lim)
+    assert not bad, bad
