@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MG_ABI_VERSION 5
+#define MG_ABI_VERSION 6
 
 enum { MG_F32 = 0, MG_BF16 = 1 };
 enum { MG_ACT_NONE = 0, MG_ACT_RELU = 1, MG_ACT_LRELU = 2, MG_ACT_TANH = 3 };
@@ -475,6 +475,31 @@ int mg_orient_loss_bwd(const float* conf_raw, const uint8_t* idx, const float* l
                        const float* hair, int64_t hair_nstride, const float* g_orient, const float* g_conf, const float* fwd_out,
                        int32_t N, int64_t HW, float* dconf, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * (iv) Collectives over RCCL / xGMI -- SURVEY.md section 8b's last export group.  One communicator per process (= per GPU); what the
+ * reference does with Python threads inside ONE process is replaced by these in a one-process-per-GPU job:
+ *   mg_allreduce_stats   sync_batchnorm/batchnorm.py:105-126 (_data_parallel_master: the master sums every replica's [sum x | sum x^2]
+ *                        -- ReduceAddCoalesced, :117 -- and broadcasts mean / inv_std back, :120) and comm.py:49-53,102-133 (the
+ *                        SyncMaster / SlavePipe rendez-vous): ONE in-place sum all-reduce of the [2C] vector, fp64 in forward
+ *                        (`is_f64` = 1), fp32 for the backward's [sum dxhat | sum dxhat * xhat] (`is_f64` = 0); every rank then runs the
+ *                        same finalize kernel (mg_channel_stats_finalize / mg_norm_finalize) on the reduced sums.
+ *   mg_allreduce_grads   the backward of nn.DataParallel's replicate / gather (pix2pix_trainer.py:21-24: gradients reduce-added onto
+ *                        GPU 0) as an in-place fp32 sum all-reduce of one contiguous gradient bucket (the 1/world average is folded
+ *                        into mg_adam_step's `grad_scale`).
+ * Both enqueue on `stream` and return; nothing synchronises.  RCCL is bound at run time (dlopen of librccl.so.1 -- inside a PyTorch-ROCm
+ * process that is the copy torch already loaded, so both share one runtime); a process without RCCL gets MG_ERR_UNSUPPORTED from
+ * mg_comm_unique_id / mg_comm_init and never needs the library otherwise.
+ *   rendez-vous: rank 0 calls mg_comm_unique_id and hands the 128 bytes to the other ranks out of band (the launcher's store /
+ *   torch.distributed broadcast / a file); every rank then calls mg_comm_init(id, rank, world) with ITS device current.
+ * ------------------------------------------------------------------------- */
+#define MG_COMM_ID_BYTES 128
+int mg_comm_unique_id(void* id_out /* host, MG_COMM_ID_BYTES */);
+int mg_comm_init(const void* id /* host, MG_COMM_ID_BYTES */, int32_t rank, int32_t world, int64_t* comm_out);
+int mg_comm_destroy(int64_t comm);
+int mg_comm_world(int64_t comm, int32_t* rank_out, int32_t* world_out);
+int mg_allreduce_stats(int64_t comm, void* sums /* device, [n] fp64 or fp32, in place */, int64_t n, int32_t is_f64, void* stream);
+int mg_allreduce_grads(int64_t comm, float* bucket /* device, [n] fp32, in place */, int64_t n, void* stream);
+
 /* Hardware probes used by the test-suite (MFMA / ds_read_tr fragment maps). */
 int mg_probe_mfma_layout(float* out /* [3][64][16] */, void* stream);
 int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* out /* [64][4] */, void* stream);
@@ -493,7 +518,8 @@ int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* o
  * the weight gradients, which use fp32 atomics).
  * MEASUREMENT builds (wrong or no results, timing only; tools/probe_halo.py, tools/probe_wgrad3x3.py): key 10 = 1..6 variants of the big
  * halo tile (K loop only / no weight stream / no barrier / per-tap stamps / per-phase stamps / stores off), 12 = 1 stamped build of the
- * 3x3 weight-gradient kernel, 13 and 14 = low and high half of the device address the stamps go to.  All default 0. */
+ * 3x3 weight-gradient kernel, 13 and 14 = low and high half of the device address the stamps go to, 21 = bytes of extra dynamic LDS per
+ * halo-conv workgroup (81920 leaves ONE resident per CU = one wave per SIMD: tools/gate1_lone_wave.py).  All default 0. */
 int         mg_set_option(int32_t key, int32_t value);
 
 /* sizeof(mg_conv_desc) (which=0) / sizeof(mg_wgrad_desc) (which=1): lets a

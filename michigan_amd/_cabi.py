@@ -15,7 +15,8 @@ MG_F32, MG_BF16 = 0, 1
 MG_ACT_NONE, MG_ACT_RELU, MG_ACT_LRELU, MG_ACT_TANH = 0, 1, 2, 3
 MG_EPI_PLAIN, MG_EPI_SPADE = 0, 1
 MG_MAX_TAPS = 64
-MG_ABI_VERSION = 5
+MG_ABI_VERSION = 6
+MG_COMM_ID_BYTES = 128
 
 _i32, _f32, _vp, _i64 = ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
 
@@ -153,6 +154,12 @@ _PROTOS = {
     "mg_nearest_table": ([_i32, _i32, _vp], _i32),
     "mg_orient_rgb_table": ([_vp], _i32),
     "mg_noise_field_len": ([_i32], _i64),
+    "mg_comm_unique_id": ([_vp], _i32),
+    "mg_comm_init": ([_vp, _i32, _i32, ctypes.POINTER(_i64)], _i32),
+    "mg_comm_destroy": ([_i64], _i32),
+    "mg_comm_world": ([_i64, ctypes.POINTER(_i32), ctypes.POINTER(_i32)], _i32),
+    "mg_allreduce_stats": ([_i64, _vp, _i64, _i32, _vp], _i32),
+    "mg_allreduce_grads": ([_i64, _vp, _i64, _vp], _i32),
     "mg_probe_mfma_layout": ([_vp, _vp], _i32),
     "mg_probe_tr16": ([_vp, _vp, _vp], _i32),
     "mg_set_option": ([_i32, _i32], _i32),

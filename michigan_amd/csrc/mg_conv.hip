@@ -26,6 +26,7 @@ extern int g_mg_wgrad_min_stages;  // mg_wgrad.hip (mg_set_option(18, v))
 extern int g_mg_conv_thin;         // mg_conv_thin.hip (mg_set_option(6, v))
 extern int g_mg_conv_dot;          // mg_conv_dot.hip (mg_set_option(8, v))
 int g_mg_conv_noxpre = 0;        // mg_set_option(15, 1): A/B switch, the SPADE halo kernel loads x in its epilogue instead of ahead of the main loop
+int g_mg_conv_halo_ldspad = 0;  // MEASUREMENT ONLY (mg_set_option(21, bytes), MG_PROBES builds): extra dynamic LDS per halo workgroup -> fewer residents per CU
 int g_mg_conv_dbg_noepi = 0;     // MEASUREMENT ONLY (mg_set_option(10, 1)): the halo kernel returns before its epilogue -- wrong results, main-loop time
 int g_mg_conv_wide = 1;          // bf16 epilogues store 16 bytes per lane after a half-wave quad exchange (mg_set_option(7, v))
 int g_mg_conv_pipeline = 1;      // 0 = register-staged double buffer, 1 = LDS-DMA 3-stage ring (mg_set_option(0, v))
@@ -604,6 +605,7 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 14) { const unsigned long long a = ((unsigned long long)(unsigned)value << 32) | g_probe_lo; const int r = conv_halo_set_probe(a); return r != MG_OK ? r : wgrad3x3_set_probe(a); }
     if (key == 12 && (value == 0 || value == 1)) { g_mg_wgrad3x3_probe = value; return MG_OK; }
     if (key == 10 && value >= 0 && value <= 6) { g_mg_conv_dbg_noepi = value; return MG_OK; }
+    if (key == 21 && value >= 0 && value <= 80 * 1024) { g_mg_conv_halo_ldspad = value; return MG_OK; }
 #endif
     return mg_fail(MG_ERR_ARG, "mg_set_option: unknown key/value %d/%d", key, value);
 }

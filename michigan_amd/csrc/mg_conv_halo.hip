@@ -33,6 +33,7 @@
 
 extern int g_mg_conv_halo_big;     // mg_set_option(4, v): 0 = never use the 128 x 16x16 geometry
 extern int g_mg_conv_dbg_noepi;    // mg_set_option(10, v): 0 product; 1 main loop only; 2..4 probes of the big tile (below)
+extern int g_mg_conv_halo_ldspad;  // mg_set_option(21, bytes), MG_PROBES builds: pad the dynamic LDS request (one resident per CU = one wave per SIMD)
 
 namespace {
 
@@ -396,10 +397,14 @@ int launch_halo_g(ConvK& k, hipStream_t st)
     const long nblk = (long)k.N * k.tiles_y * k.tiles_x * k.tiles_m;
     if (nblk <= 0 || nblk > 0x7fffffffL) return mg_fail(MG_ERR_ARG, "mg_conv_taps(halo): bad grid %ld", nblk);
     auto kern = conv3x3_halo_kernel<T, EPI, WM, NT, PROBE>;
-    if constexpr (G::LDS > 65536) {
-        mg_raise_lds_cap(reinterpret_cast<const void*>(kern), G::LDS);
+    int lds = G::LDS;
+#if MG_PROBES
+    lds += g_mg_conv_halo_ldspad;
+#endif
+    if (lds > 65536) {
+        mg_raise_lds_cap(reinterpret_cast<const void*>(kern), lds);
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NTHR), G::LDS, st, k);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(NTHR), lds, st, k);
     MG_CHECK_LAUNCH("mg_conv_taps(halo)");
     return MG_OK;
 }

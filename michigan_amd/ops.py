@@ -66,7 +66,13 @@ def _sync_bn_all_reduce(t: torch.Tensor, kind: str):
     if ev is not None:
         s = torch.cuda.Event(enable_timing=True)
         s.record()
-    work = dist.all_reduce(t, group=SYNC_BN_GROUP, async_op=SYNC_BN_ASYNC)
+    from . import parallel
+    nat = parallel.native_comm() if t.is_cuda else None
+    if nat is not None:
+        nat.all_reduce_stats(t)                           # include/michigan_hip.h group (iv): RCCL on the current stream, no torch.distributed call
+        work = None
+    else:
+        work = dist.all_reduce(t, group=SYNC_BN_GROUP, async_op=SYNC_BN_ASYNC)
     if ev is not None:
         e = torch.cuda.Event(enable_timing=True)
         e.record()

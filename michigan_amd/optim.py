@@ -329,7 +329,12 @@ class FlatAdam:
         from . import parallel
         parallel.COLLECTIVES["grad_bucket"] += 1
         self._launched_any = True
-        if chunk.is_cuda and GRAD_SIDE_STREAM == 2:
+        if chunk.is_cuda and parallel.native_comm() is not None:
+            # MG_COMM=native: mg_allreduce_grads on the communicator's own stream (MG_DP_GRAD_SIDE=0: on the current stream)
+            w = parallel.all_reduce_grads(chunk, self.group, async_op=bool(GRAD_SIDE_STREAM))
+            if w is not None:
+                self._work.append(w)
+        elif chunk.is_cuda and GRAD_SIDE_STREAM == 2:
             self._work.append(dist.all_reduce(chunk, group=self.group, async_op=True))     # the process group's own stream, no extra side stream
         elif chunk.is_cuda and not GRAD_SIDE_STREAM:
             dist.all_reduce(chunk, group=self.group, async_op=False)        # on the current stream (torch >= 2.8), in issue order

@@ -41,10 +41,95 @@ import torch.distributed as dist
 
 from . import ops
 
+# MG_COMM=native: the sync-BN and gradient all-reduces go through the C ABI's own RCCL entry points (include/michigan_hip.h group iv:
+# mg_comm_init / mg_allreduce_stats / mg_allreduce_grads) instead of torch.distributed's; torch.distributed stays the launcher-side
+# rendez-vous (it carries the 128-byte RCCL id from rank 0 to the others once) and the route of everything that is not on the step's
+# critical path (parameter broadcast at start-up, checkpoint barriers, the shared RNG seed).
+NATIVE_COMM = os.environ.get("MG_COMM", "torch") == "native"
+_NATIVE = None           # NativeComm of this process, when NATIVE_COMM and the tensors live on a GPU
+
 _GROUP = None            # gradient buckets
 _BN_GROUP = None         # sync-BN statistics (a second communicator over the same ranks)
 _OWNED = []              # groups init() created (destroyed by shutdown())
 _SHARED_RNG: Optional[random.Random] = None       # host-side draws every rank must make identically (see shared_rng)
+
+
+class NativeComm:
+    """One RCCL communicator of libmichigan_hip.so over the ranks of a torch.distributed group (mg_comm_init)."""
+
+    class _Work:
+        """What `dist.all_reduce(..., async_op=True)` returns, for a collective issued on the communicator's own stream."""
+
+        def __init__(self, event):
+            self.event = event
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.event)
+
+    def __init__(self, group):
+        import ctypes
+        from . import _cabi
+        self.be = _cabi.backend()
+        if self.be.name != "hip":
+            raise RuntimeError("MG_COMM=native needs the HIP backend")
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        buf = ctypes.create_string_buffer(_cabi.MG_COMM_ID_BYTES)
+        if self.rank == 0:
+            self.be.mg_comm_unique_id(buf)
+        box = [bytes(buf.raw)]
+        src = dist.get_global_rank(group, 0) if group is not dist.group.WORLD else 0
+        dist.broadcast_object_list(box, src=src, group=group)
+        handle = ctypes.c_int64(0)
+        self.be.mg_comm_init(ctypes.create_string_buffer(box[0], _cabi.MG_COMM_ID_BYTES), self.rank, self.world, ctypes.byref(handle))
+        self.handle = handle.value
+        r, w = ctypes.c_int32(-1), ctypes.c_int32(-1)
+        self.be.mg_comm_world(self.handle, ctypes.byref(r), ctypes.byref(w))
+        assert (r.value, w.value) == (self.rank, self.world)
+        self.stream = None                                   # gradient buckets: the communicator's own stream (created on first use)
+        self.calls = {"stats": 0, "grads": 0}
+
+    def all_reduce_stats(self, t: torch.Tensor):
+        """In place, on the CURRENT stream (the sync-BN reductions sit on the critical path: no stream hop)."""
+        import ctypes
+        assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float64, torch.float32)
+        self.calls["stats"] += 1
+        self.be.mg_allreduce_stats(self.handle, t.data_ptr(), t.numel(), int(t.dtype == torch.float64),
+                                   ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream))
+
+    def all_reduce_grads(self, chunk: torch.Tensor, async_op: bool = True):
+        """In place fp32 sum of one contiguous bucket.  async_op: on the communicator's own stream, ordered behind the current stream's
+        work so far; the returned work's wait() orders the current stream behind the collective (like a ProcessGroup's async work)."""
+        import ctypes
+        assert chunk.is_cuda and chunk.is_contiguous() and chunk.dtype == torch.float32
+        cur = torch.cuda.current_stream(chunk.device)
+        self.calls["grads"] += 1
+        if not async_op:
+            self.be.mg_allreduce_grads(self.handle, chunk.data_ptr(), chunk.numel(), ctypes.c_void_p(cur.cuda_stream))
+            return None
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=chunk.device)
+        self.stream.wait_stream(cur)
+        self.be.mg_allreduce_grads(self.handle, chunk.data_ptr(), chunk.numel(), ctypes.c_void_p(self.stream.cuda_stream))
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return NativeComm._Work(ev)
+
+    def destroy(self):
+        if self.handle:
+            torch.cuda.synchronize()
+            self.be.mg_comm_destroy(self.handle)
+            self.handle = 0
+
+
+def native_comm():
+    return _NATIVE
+
+
+def all_reduce_grads(chunk, group, async_op=True):
+    """The gradient buckets' all-reduce: the C ABI's RCCL entry point under MG_COMM=native (GPU tensors), else torch.distributed's."""
+    if _NATIVE is not None and chunk.is_cuda:
+        return _NATIVE.all_reduce_grads(chunk, async_op=async_op)
+    return dist.all_reduce(chunk, group=group, async_op=async_op)
 
 
 def _forced() -> bool:
@@ -59,7 +144,7 @@ def init(group=None):
     Collective over those ranks (it creates process groups).  Returns the gradient group, or None when there is
     nothing to reduce (no process group / one rank).  Idempotent for the same `group`."""
     global _GROUP, _BN_GROUP
-    global _SHARED_RNG
+    global _SHARED_RNG, _NATIVE
     if not _forced() and (not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1):
         _GROUP = _BN_GROUP = _SHARED_RNG = None
         ops.SYNC_BN_GROUP = None
@@ -79,6 +164,8 @@ def init(group=None):
         _OWNED.append(_BN_GROUP)
     ops.SYNC_BN_GROUP = None if os.environ.get("MG_DP_NO_SYNCBN") == "1" else _BN_GROUP      # measurement switch
     _init_shared_rng(base)
+    if NATIVE_COMM and torch.cuda.is_available() and _NATIVE is None:
+        _NATIVE = NativeComm(base)
     return _GROUP
 
 
@@ -118,8 +205,11 @@ def shutdown():
         except Exception:                                  # the default group went first: nothing left to destroy
             pass
     del _OWNED[:]
-    global _SHARED_RNG
+    global _SHARED_RNG, _NATIVE
     _SHARED_RNG = None
+    if _NATIVE is not None:
+        _NATIVE.destroy()
+        _NATIVE = None
     _GROUP = _BN_GROUP = None
     init._base = None
     ops.SYNC_BN_GROUP = None
@@ -269,7 +359,7 @@ class GradAverager:
         lo, hi = self.buckets[i]
         self._launched[i] = True
         COLLECTIVES["grad_bucket"] += 1
-        self._work.append(dist.all_reduce(self.flat[lo:hi], group=self.group, async_op=True))
+        self._work.append(all_reduce_grads(self.flat[lo:hi], self.group, async_op=True))
 
     def _wait(self):
         for w in self._work:

@@ -115,6 +115,8 @@ def main(mode):
         trainer = RefLikeTrainer(opt, device)
         assert len(trainer.pix2pix_model.grad_averagers) == 2
     assert parallel.world_size() == world and ops.SYNC_BN_GROUP is parallel.bn_group()
+    native = os.environ.get("MG_COMM") == "native"
+    assert (parallel.native_comm() is not None) == (native and device.type == "cuda")          # include/michigan_hip.h group (iv) instead of torch.distributed
     assert (parallel.bn_group() is not parallel.grad_group()) == (os.environ.get("MG_DP_TWO_GROUPS") == "1")    # the second communicator is opt-in
     TP.load_weights(trainer, cfg)
     parallel.reset_collective_counts()
@@ -171,9 +173,13 @@ def main(mode):
             assert torch.equal(ref, t.detach()), "rank %d diverged from rank 0 in %s" % (rank, name)
     c = parallel.COLLECTIVES
     assert c["syncbn_fwd"] > 0 and c["syncbn_bwd"] > 0 and 0 < c["grad_bucket"] <= 16 * cfg["iters"], c
+    nat = parallel.native_comm()
+    if nat is not None:                                        # every counted collective of the step went through mg_allreduce_*
+        assert nat.calls["stats"] == c["syncbn_fwd"] + c["syncbn_bwd"] and nat.calls["grads"] == c["grad_bucket"], (nat.calls, c)
     dist.barrier()
     if rank == 0:
-        print("DP_WORKER_OK mode=%s%s world=%d backend=%s collectives=%s per_step=%s" % (mode, "_bf16" if bf16 else "", world, backend, dict(c), per_step[-1]), flush=True)
+        print("DP_WORKER_OK mode=%s%s world=%d backend=%s collectives=%s per_step=%s native_calls=%s" % (mode, "_bf16" if bf16 else "", world, backend, dict(c), per_step[-1], nat.calls if nat is not None else None), flush=True)
+    parallel.shutdown()
     dist.destroy_process_group()
 
 

@@ -59,6 +59,13 @@ def test_argument_validation_without_gpu(lib_path):
         be.mg_conv_wgrad(w, None)
     with pytest.raises(RuntimeError, match="bad geometry"):
         be.mg_channel_stats(64, _cabi.MG_F32, 1, 100, 6, 1, 64, 64, None)
+    # group (iv), collectives: arguments are checked before RCCL is even looked for
+    with pytest.raises(RuntimeError, match="null"):
+        be.mg_comm_unique_id(None)
+    with pytest.raises(RuntimeError, match="null communicator"):
+        be.mg_allreduce_stats(0, 64, 16, 1, None)
+    with pytest.raises(RuntimeError, match="null communicator"):
+        be.mg_allreduce_grads(0, 64, 16, None)
 
 
 def test_kernels_are_gfx950_code_objects(lib_path):

@@ -12,6 +12,7 @@
     group's stream, pre-step wait + scale) on the real kernels of a one-GPU box.  (The FlatAdam consumer's one-rank run is
     tests/test_gpu_trainer.py::test_trainer_with_forced_one_rank_rccl_matches_golden.)
 """
+import ctypes
 import os
 import subprocess
 import sys
@@ -74,3 +75,56 @@ def test_two_ranks_sharing_one_gpu_two_communicators(hip_backend):
 def test_one_rank_forced_rccl_reference_flow_matches_golden(hip_backend):
     out = _launch("reflike", 1, 29634, {"MG_DP_FORCE": "1"})
     assert "world=1" in out
+
+
+# ---- include/michigan_hip.h group (iv): mg_comm_init / mg_allreduce_stats / mg_allreduce_grads (SURVEY section 8b item iv) ----------------------
+
+def test_cabi_comm_world_one_all_reduces_in_place(hip_backend):
+    """The C ABI's own RCCL entry points without torch.distributed anywhere: unique id -> communicator of one rank on this GPU -> in-place
+    fp64 / fp32 statistics all-reduce and a gradient-bucket all-reduce on a non-default stream (a sum over one rank leaves the values as
+    they are -- bit for bit) -> destroy.  What a foreign-language host would call."""
+    from michigan_amd import _cabi
+    be = hip_backend
+    uid = ctypes.create_string_buffer(_cabi.MG_COMM_ID_BYTES)
+    be.mg_comm_unique_id(uid)
+    assert any(uid.raw)
+    h = ctypes.c_int64(0)
+    be.mg_comm_init(uid, 0, 1, ctypes.byref(h))
+    assert h.value != 0
+    r, w = ctypes.c_int32(-1), ctypes.c_int32(-1)
+    be.mg_comm_world(h.value, ctypes.byref(r), ctypes.byref(w))
+    assert (r.value, w.value) == (0, 1)
+    g = torch.Generator().manual_seed(3)
+    s64 = torch.randn(2048, generator=g, dtype=torch.float64).cuda()
+    s32 = torch.randn(2048, generator=g).cuda()
+    bucket = torch.randn(16 << 20, generator=g).cuda()                       # one 64 MiB gradient bucket
+    want = (s64.clone(), s32.clone(), bucket.clone())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    cur = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    be.mg_allreduce_stats(h.value, s64.data_ptr(), s64.numel(), 1, cur)
+    be.mg_allreduce_stats(h.value, s32.data_ptr(), s32.numel(), 0, cur)
+    be.mg_allreduce_grads(h.value, bucket.data_ptr(), bucket.numel(), ctypes.c_void_p(side.cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(s64, want[0]) and torch.equal(s32, want[1]) and torch.equal(bucket, want[2])
+    with pytest.raises(RuntimeError, match="null"):
+        be.mg_allreduce_grads(h.value, None, 16, cur)
+    with pytest.raises(RuntimeError, match="bad rank"):
+        be.mg_comm_init(uid, 2, 2, ctypes.byref(ctypes.c_int64(0)))
+    be.mg_comm_destroy(h.value)
+
+
+@pytest.mark.parametrize("mode", ["repo", "reflike"])
+def test_one_rank_native_comm_trainer_matches_golden(hip_backend, mode):
+    """MG_COMM=native: the trainer's 42 sync-BN all-reduces and its gradient buckets per step go through mg_allreduce_stats /
+    mg_allreduce_grads (one rank, every collective forced) and reproduce the reference trainer's goldens; the worker asserts that the
+    native call counts equal the collective counts, i.e. that no all-reduce of the step took the torch.distributed route."""
+    out = _launch(mode, 1, 29641 if mode == "repo" else 29642, {"MG_DP_FORCE": "1", "MG_COMM": "native"})
+    assert "world=1" in out and "native_calls={" in out
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (self-enabling on a multi-GPU node)")
+@pytest.mark.parametrize("mode", ["repo", "reflike"])
+def test_two_rank_native_comm_trainer_matches_golden(hip_backend, mode):
+    out = _launch(mode, 2, 29643 if mode == "repo" else 29644, {"MG_COMM": "native"})
+    assert "world=2" in out and "native_calls={" in out
