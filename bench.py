@@ -285,6 +285,7 @@ def main():
     if world > 1:
         barrier()
     torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -302,6 +303,7 @@ def main():
         own[rank] = dt_own / a.steps * 1e3
         dist.all_reduce(own)                                    # every rank's own ms/step: the spread shows a straggler / a stalled communicator
         per_rank_ms = [round(v, 3) for v in own.tolist()]
+    peak_mem = {"timed_region": round(torch.cuda.max_memory_allocated() / 1e9, 2)}     # the side stream keeps operands referenced longer
     losses = {k: float(v.detach().float().mean()) for k, v in trainer.get_latest_losses().items()}
     step_gflop_ref = STEP_GFLOP_REFERENCE if a.mode == "train" else F_G
     step_gflop_min = STEP_GFLOP_MINIMUM if a.mode == "train" else F_G
@@ -313,8 +315,12 @@ def main():
         from michigan_amd import ops as _ops, parallel as _par
         _par.reset_collective_counts()
         _ops.SYNC_BN_EVENTS = [] if (world > 1 or os.environ.get("MG_DP_FORCE") == "1") else None
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
         with ConvMeter() as m:
             step()
+        torch.cuda.synchronize()
+        peak_mem["single_stream_step"] = round(torch.cuda.max_memory_allocated() / 1e9, 2)
         n, ms, fl, (dn, dms, dfl, dbytes) = m.summary()
         collectives = dict(_par.COLLECTIVES)
         syncbn_ms = None
@@ -399,6 +405,7 @@ def main():
                                       "vs_minimum_work": round(value * step_gflop_min / 1e3 / world, 1),
                                       "gflop_per_image": [step_gflop_ref, step_gflop_min], "unit": "TFLOP/s per GPU"},
             "losses": losses,
+            "peak_memory_gb": peak_mem,                         # torch.cuda.max_memory_allocated: the timed region (streams as configured) / the extra single-stream step
         }
         if per_rank_ms is not None:
             out["per_rank_ms_per_step"] = per_rank_ms           # each rank's own clock up to its last kernel; `ms_per_step` is the max incl. the barrier

@@ -23,7 +23,7 @@ OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libmichigan_hip.so")
 
 ARCH = "gfx950"
-SOURCES = ["mg_api.hip", "mg_conv.hip", "mg_wgrad.hip", "mg_norm.hip", "mg_pointwise.hip", "mg_pack.hip", "mg_conv_halo.hip", "mg_gabor.hip", "mg_wgrad3x3.hip", "mg_spectral.hip", "mg_conv_thin.hip", "mg_inputs.hip", "mg_conv_dot.hip", "mg_loss.hip", "mg_grad.hip", "mg_weights.hip", "mg_glue.hip", "mg_attention.hip", "mg_comm.hip"]
+SOURCES = ["mg_api.hip", "mg_conv.hip", "mg_wgrad.hip", "mg_norm.hip", "mg_pointwise.hip", "mg_pack.hip", "mg_conv_halo.hip", "mg_conv_halo64.hip", "mg_gabor.hip", "mg_wgrad3x3.hip", "mg_spectral.hip", "mg_conv_thin.hip", "mg_inputs.hip", "mg_conv_dot.hip", "mg_loss.hip", "mg_grad.hip", "mg_weights.hip", "mg_glue.hip", "mg_attention.hip", "mg_comm.hip"]
 CXXFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
             "-fno-gpu-rdc", f"-I{INCLUDE}", f"-I{CSRC}"]
 

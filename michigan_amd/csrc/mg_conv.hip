@@ -25,6 +25,8 @@ extern int g_mg_norm_bwd_vec;      // mg_norm.hip (mg_set_option(19, v))
 extern int g_mg_wgrad_min_stages;  // mg_wgrad.hip (mg_set_option(18, v))
 extern int g_mg_conv_thin;         // mg_conv_thin.hip (mg_set_option(6, v))
 extern int g_mg_conv_dot;          // mg_conv_dot.hip (mg_set_option(8, v))
+extern int g_mg_conv_halo64;       // mg_conv_halo64.hip (mg_set_option(22, v))
+extern int g_mg_conv_halo64_dbg;   // mg_conv_halo64.hip (mg_set_option(23, bits)): measurement only
 int g_mg_conv_noxpre = 0;        // mg_set_option(15, 1): A/B switch, the SPADE halo kernel loads x in its epilogue instead of ahead of the main loop
 int g_mg_conv_halo_ldspad = 0;  // MEASUREMENT ONLY (mg_set_option(21, bytes), MG_PROBES builds): extra dynamic LDS per halo workgroup -> fewer residents per CU
 int g_mg_conv_dbg_noepi = 0;     // MEASUREMENT ONLY (mg_set_option(10, 1)): the halo kernel returns before its epilogue -- wrong results, main-loop time
@@ -531,6 +533,7 @@ int dispatch_conv(ConvK& k, int epilogue, hipStream_t st)
     if (conv_thin_taps_applies(k, ET<T>::DT, epilogue)) return launch_conv_thin_taps(k, st);
     if (conv_dot_applies(k, ET<T>::DT, epilogue)) return launch_conv_dot(k, ET<T>::DT, st);
     if (conv_fewout_applies(k, ET<T>::DT, epilogue)) return launch_conv_fewout(k, st);
+    if (conv_halo64_applies(k, ET<T>::DT, epilogue)) return launch_conv_halo64(k, st);
     if (halo_applies<T>(k)) return launch_conv_halo(k, ET<T>::DT, epilogue, st);
     return epilogue == MG_EPI_SPADE ? dispatch_tiles<T, MG_EPI_SPADE>(k, st) : dispatch_tiles<T, MG_EPI_PLAIN>(k, st);
 }
@@ -607,5 +610,7 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
     if (key == 10 && value >= 0 && value <= 6) { g_mg_conv_dbg_noepi = value; return MG_OK; }
     if (key == 21 && value >= 0 && value <= 80 * 1024) { g_mg_conv_halo_ldspad = value; return MG_OK; }
 #endif
+    if (key == 22 && (value == 0 || value == 1)) { g_mg_conv_halo64 = value; return MG_OK; }
+    if (key == 23 && value >= 0 && value <= 7) { g_mg_conv_halo64_dbg = value; return MG_OK; }
     return mg_fail(MG_ERR_ARG, "mg_set_option: unknown key/value %d/%d", key, value);
 }

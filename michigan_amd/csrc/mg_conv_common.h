@@ -707,6 +707,8 @@ struct LinearPixMap {
 }  // namespace
 
 int launch_conv_halo(ConvK& k, int dtype, int epilogue, hipStream_t st);   // mg_conv_halo.hip
+bool conv_halo64_applies(const ConvK& k, int dtype, int epilogue);          // mg_conv_halo64.hip: 3x3 over exactly 64 input channels, weights in registers
+int launch_conv_halo64(ConvK& k, hipStream_t st);
 bool conv_thin_applies(const ConvK& k, int dtype, int epilogue);            // mg_conv_thin.hip
 int launch_conv_thin(ConvK& k, hipStream_t st);
 bool conv_thin_taps_applies(const ConvK& k, int dtype, int epilogue);       // mg_conv_thin.hip: any <= 7x7 window, stride 1 | 2

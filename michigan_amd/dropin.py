@@ -102,32 +102,15 @@ def _save_network_rank0(net, label, epoch, opt):
     then `torch.save` to the same `<epoch>_net_<label>.pth` concurrently -- which can leave a torn file.  Here rank 0 writes a CPU copy
     of the state_dict to a temporary file and renames it into place (readers see the old or the new checkpoint, never a partial one),
     the other ranks hold identical weights and only wait at the barrier; the network stays on its device."""
-    import torch.distributed as dist
+    from . import parallel
     rank, world = _rank_world()
     path = os.path.join(opt.checkpoints_dir, opt.name, "%s_net_%s.pth" % (epoch, label))
-    err = None
-    if rank == 0:
-        tmp = "%s.tmp.%d" % (path, os.getpid())
-        try:
-            os.makedirs(os.path.dirname(path), exist_ok=True)
-            sd = {k: v.detach().to("cpu", copy=True) for k, v in net.state_dict().items()}
-            torch.save(sd, tmp)
-            os.replace(tmp, path)
-        except Exception as e:                            # disk full, permissions ...: every rank has to learn about it (ADVICE r4)
-            err = e
-        finally:
-            if os.path.exists(tmp):
-                os.remove(tmp)
-    if world > 1:
-        # save() must be called on ALL ranks (like the reference's loop does): the outcome of rank 0's write is broadcast, so a failed
-        # write raises everywhere instead of leaving the other ranks in a barrier until the collective times out
-        dev = next(net.parameters()).device if dist.get_backend() == "nccl" else torch.device("cpu")
-        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev)
-        dist.broadcast(ok, src=0)
-        if int(ok.item()) == 0 and err is None:
-            raise RuntimeError("michigan_amd.dropin: rank 0 failed to write %s" % path)
-    if err is not None:
-        raise err
+    sd = {k: v.detach().to("cpu", copy=True) for k, v in net.state_dict().items()} if rank == 0 else None
+    # save() must be called on ALL ranks (like the reference's loop does): the outcome of rank 0's write is broadcast, so a failed write
+    # raises everywhere instead of leaving the other ranks in a barrier until the collective times out (ADVICE r4)
+    import torch.distributed as dist
+    group = dist.group.WORLD if (world > 1 and parallel.grad_group() is None) else None
+    parallel.rank0_write(path, lambda tmp: torch.save(sd, tmp), group=group, device=next(net.parameters()).device)
 
 
 class _EpochShardSampler(torch.utils.data.distributed.DistributedSampler):

@@ -263,6 +263,9 @@ class Pix2PixModel(nn.Module):
             # its forward ran on and orders the accumulation at `fake`.
             side.wait_stream(main)
             fake.record_stream(side)
+            for k in ("input_tag", "orient", "image_tag"):       # every main-allocated tensor the D branch reads on the side stream
+                if torch.is_tensor(d.get(k)) and d[k].is_cuda:
+                    d[k].record_stream(side)
             with torch.cuda.stream(side):
                 pred_fake, pred_real = self.discriminate(d, fake, split=True)
                 if not self.opt.no_gan_loss:
@@ -323,17 +326,13 @@ class Pix2PixModel(nn.Module):
 
     def save(self, epoch):
         """`<epoch>_net_G.pth` / `<epoch>_net_D.pth`: plain state_dicts with the reference's keys, loadable by the reference.
-        Data parallel: rank 0 writes (temporary file + rename, so a reader never sees a torn file), everyone waits."""
-        import os
-        if parallel.rank() == 0:
-            os.makedirs(os.path.join(self.opt.checkpoints_dir, self.opt.name), exist_ok=True)
-            for label, net in (("G", self.netG), ("D", self.netD)):
-                if net is not None:
-                    path = self._ckpt_path(label, epoch)
-                    torch.save({k: v.detach().cpu() for k, v in net.state_dict().items()}, path + ".tmp")
-                    os.replace(path + ".tmp", path)
-        if parallel.grad_group() is not None:
-            torch.distributed.barrier(group=parallel.grad_group())
+        Data parallel: call on EVERY rank; rank 0 writes (temporary file + rename, so a reader never sees a torn file) and the outcome
+        is broadcast -- a failed write raises on all ranks and leaves no temporary file (parallel.rank0_write)."""
+        for label, net in (("G", self.netG), ("D", self.netD)):
+            if net is not None:
+                sd = {k: v.detach().cpu() for k, v in net.state_dict().items()} if parallel.rank() == 0 else None
+                parallel.rank0_write(self._ckpt_path(label, epoch), lambda tmp, sd=sd: torch.save(sd, tmp),
+                                     device=next(net.parameters()).device)
 
     def load(self, epoch):
         """util.load_network semantics: copy by key, skip unknown keys, strip a leading 'module.' (multi-GPU files).  The
@@ -417,9 +416,9 @@ class Pix2PixTrainer:
         torch.optim.Adam's state_dict layout, `<epoch>_optim.pth`), so that training resumes exactly."""
         import os
         self.pix2pix_model_on_one_gpu.save(epoch)
-        if parallel.rank() == 0:
-            torch.save({"G": self.optimizer_G.state_dict(), "D": self.optimizer_D.state_dict(), "old_lr": self.old_lr},
-                       os.path.join(self.opt.checkpoints_dir, self.opt.name, "%s_optim.pth" % epoch))
+        sd = {"G": self.optimizer_G.state_dict(), "D": self.optimizer_D.state_dict(), "old_lr": self.old_lr} if parallel.rank() == 0 else None
+        parallel.rank0_write(os.path.join(self.opt.checkpoints_dir, self.opt.name, "%s_optim.pth" % epoch), lambda tmp: torch.save(sd, tmp),
+                             device=self.optimizer_G.flat.device)
 
     def load(self, epoch):
         import os

@@ -359,7 +359,7 @@ def _grad_premasked(dh: torch.Tensor, h: torch.Tensor, act: int) -> bool:
         return False
     hit = _RELU_MASKED.pop(dh.data_ptr(), None) == (h.data_ptr(), dh._version)
     if act == ACT_LRELU and h.data_ptr() in _FOLD_EXPECTED:
-        _FOLD_EXPECTED.discard(h.data_ptr())
+        _FOLD_EXPECTED.pop(h.data_ptr(), None)
         if MASK_PROTOCOL_CHECK and not hit and FUSE_LRELU_MASK and FUSE_RELU_MASK:
             raise RuntimeError("mask protocol: the consumer of a single-consumer LeakyReLU output folded the activation's backward mask into its "
                                "data gradient, but the gradient that reached the producer is not that buffer (cloned by a hook, accumulated with "
@@ -372,8 +372,19 @@ def expire_fold_expectations():
     """A new generator forward in grad mode starts a new graph: expectations a previous forward left without ever running its backward
     (validation / visualisation passes outside no_grad, under an optimiser that never calls reset_mask_protocol: the drop-in's
     torch.optim.Adam) must not meet a recycled address later.  Only the error CHECK is keyed on them; the hand-off itself
-    (_RELU_MASKED) is untouched."""
-    _FOLD_EXPECTED.clear()
+    (_RELU_MASKED) is untouched.  Expectations whose GRAPH is still alive stay: each carries a weak reference to the autograd node that produced
+    h (a custom Function's context, kept alive by the graph and by nothing else), so a second grad-mode generator pass inside one graph does
+    not switch the check off for the first pass; entries without such a node are dropped as before."""
+    for addr in [a for a, ref in _FOLD_EXPECTED.items() if ref is None or ref() is None]:
+        del _FOLD_EXPECTED[addr]
+
+
+def _weak_node(t):
+    import weakref
+    try:
+        return weakref.ref(t.grad_fn) if t.grad_fn is not None else None
+    except TypeError:                                      # a node type without weak-reference support: the entry expires at the next forward
+        return None
 
 
 def reset_mask_protocol():
@@ -383,7 +394,7 @@ def reset_mask_protocol():
 
 
 _RELU_MASKED = {}       # address of a ReLU-masked data gradient -> (address of the ReLU output it was masked with, version)
-_FOLD_EXPECTED = set()  # addresses of LeakyReLU outputs whose (single) consumer committed to the mask fold at forward time
+_FOLD_EXPECTED = {}     # address of a LeakyReLU output whose (single) consumer committed to the mask fold at forward time -> weakref of its producer node
 _DGRAD_CLASSES = {}     # (kh, kw, stride, pad) -> [(py, px, taps, (lo, hi))], tap order of the class-sorted weight image
 _DGRAD_PERM = {}        # (kh, kw, stride, pad, device) -> index tensor that sorts the packed taps by parity class
 
@@ -484,7 +495,11 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int, stride: int,
 WGRAD_SIDE_STREAM = os.environ.get("MG_WGRAD_STREAM", "1") != "0"
 WGRAD_HALF_CU = os.environ.get("MG_WGRAD_HALF_CU", "1") != "0"     # side-stream wgrad3x3 launches keep to one workgroup per CU (flags bit 1): -0.6 / -0.55 / 0.0 ms on three boxes
 _WGRAD_BESIDE = False
-_WGRAD_STREAMS = {}            # device index -> [stream, dirty, held]: held = [(event, x, dy)] of launches that may still be running
+_WGRAD_STREAMS = {}            # device index -> [stream, dirty, held]: held = [(event, x, dy, bytes)] of launches that may still be running
+# The held operands outlive their autograd nodes while the side queue lags (the case the stream is for): their bytes are BOUNDED -- past the
+# budget the main stream waits for the oldest launches' events and lets go of them.  At bs 8 / 512^2 the whole backward holds
+# < 3 GB this way (bench.py reports torch's peak for both settings of MG_WGRAD_STREAM under `extra.peak_memory_gb`).
+WGRAD_HELD_BUDGET = int(os.environ.get("MG_WGRAD_HELD_MB", "6144")) << 20
 
 
 def _new_side_stream(device):
@@ -536,7 +551,12 @@ def sink_wgrad(arena, slot, x, dy, kh, kw, stride, pad, need_b):
         # (round 5: G_middle_1.conv_1's weight gradient at cosine 0.78 in tests/test_gpu_fullsize.py before this list existed).
         while held and held[0][0].query():
             held.pop(0)
-        held.append((ev, x, dy))
+        held.append((ev, x, dy, x.numel() * x.element_size() + dy.numel() * dy.element_size()))
+        over = sum(h[3] for h in held) - WGRAD_HELD_BUDGET
+        while over > 0 and len(held) > 1:                              # the main stream falls in behind the oldest launches: their operands are free again
+            old = held.pop(0)
+            torch.cuda.current_stream(x.device).wait_event(old[0])
+            over -= old[3]
         return
     conv_wgrad(x, dy, kh, kw, stride, pad, want_bias=need_b, out=(slot[1], slot[2]))
     arena.slot_written(slot[0])
@@ -698,7 +718,7 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if xp is x and not fold and FUSE_LRELU_MASK and getattr(x, "_mg_lrelu_out", None) is not None:
         fold, mslope = True, float(x._mg_lrelu_out)             # a LeakyReLU output whose producer named this conv its only consumer
         if torch.is_grad_enabled() and x.requires_grad and FUSE_RELU_MASK:
-            _FOLD_EXPECTED.add(x.data_ptr())                    # this conv's data gradient WILL carry x's mask: its producer must find it so
+            _FOLD_EXPECTED[x.data_ptr()] = _weak_node(x)         # this conv's data gradient WILL carry x's mask: its producer must find it so
     y = _Conv2dFn.apply(xp, weight, bias, resid, stride, padding, act, slope, fold, _sink_for(weight, bias), mslope)
     if act == ACT_RELU:
         y._mg_relu_out = True        # consumers may fold this ReLU's backward mask into their data-gradient epilogue

@@ -240,6 +240,36 @@ def reset_collective_counts():
         COLLECTIVES[k] = 0
 
 
+def rank0_write(path: str, write, group=None, device=None):
+    """`write(tmp_path)` on rank 0 into a temporary file that is renamed over `path` (a reader sees the old or the new file, never a torn one);
+    the OUTCOME is broadcast so that a failed write (disk full, permissions) raises on every rank instead of leaving the others in a barrier
+    until the collective times out.  Collective over `group` (default: the gradient group; single process: just the atomic write).  Used by the
+    drop-in's util.save_network replacement and by model.Pix2PixModel.save / Pix2PixTrainer.save."""
+    g = group if group is not None else _GROUP
+    in_job = g is not None and dist.is_available() and dist.is_initialized()
+    r = dist.get_rank(g) if in_job else 0
+    err = None
+    if r == 0:
+        tmp = "%s.tmp.%d" % (path, os.getpid())
+        try:
+            os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+            write(tmp)
+            os.replace(tmp, path)
+        except Exception as e:
+            err = e
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    if in_job and dist.get_world_size(g) > 1:
+        dev = device if (device is not None and dist.get_backend(g) == "nccl") else torch.device("cpu")
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev)
+        dist.broadcast(ok, src=dist.get_global_rank(g, 0) if g is not dist.group.WORLD else 0, group=g)
+        if int(ok.item()) == 0 and err is None:
+            raise RuntimeError("michigan_amd: rank 0 failed to write %s" % path)
+    if err is not None:
+        raise err
+
+
 def broadcast_parameters(module, src: int = 0, group=None):
     """Make every rank start from rank `src`'s weights and buffers (done once, not per forward -- the reference
     re-broadcasts 0.63 GB per replica in every DataParallel.forward).  Tensors are coalesced per dtype into flat

@@ -1311,3 +1311,89 @@ def test_self_attention_matches_contract(hip_backend, dt):
         (hip, _), (ref, _) = _both(fn, (q, k, v))
         assert torch.equal(hip[0][:, :, :256].cpu(), torch.zeros_like(ref[0][:, :, :256])), "wrote outside its half of the rows"
         _close(f"self_attention {dt} n={n} L={L}", hip[0][:, :, 256:], ref[0][:, :, 256:], tol)
+
+
+def test_halo64_matches_the_shipped_halo_kernel_bitwise(hip_backend):
+    """csrc/mg_conv_halo64.hip (3x3 convolutions over exactly 64 input channels: weights in registers, strips of 16x16 tiles per workgroup)
+    against the kernel it replaces (mg_set_option(22, 0): conv3x3_halo_kernel<bf16, PLAIN, 1, 2> / <2, 2>): same K order, so BITWISE equal --
+    every epilogue case it takes ({no aux} x {none, relu, lrelu}, residual, ReLU mask and LeakyReLU mask of a data gradient), 64 -> 64 and
+    64 -> 128, several strip splits (batch 1: eight segments per row band; batch 3: an odd number of workgroups, no XCD remap), non-square
+    images, image borders on all four sides; and against the float64 contract for one case.  Shapes that the new kernel does not take
+    (ragged tiles, too few tiles) must still run (on the shipped kernel)."""
+    from michigan_amd import ops
+    be = hip_backend
+    g = torch.Generator().manual_seed(11)
+
+    def both(fn):
+        outs = []
+        for on in (1, 0):
+            be.mg_set_option(22, on)
+            try:
+                outs.append(fn().clone())
+            finally:
+                be.mg_set_option(22, 1)
+        torch.cuda.synchronize()
+        return outs
+
+    launches = {"n": 0}
+    orig = be.mg_conv_taps
+    for n, h, w, cout in ((1, 512, 512, 64), (3, 256, 384, 64), (8, 512, 512, 64), (2, 512, 512, 128), (4, 256, 512, 64)):
+        x = torch.randn(n, h, w, 64, generator=g).to(torch.bfloat16).cuda()
+        wt = (torch.randn(cout, 64, 3, 3, generator=g) * 0.05).cuda()
+        b = torch.randn(cout, generator=g).cuda()
+        res = torch.randn(n, h, w, cout, generator=g).to(torch.bfloat16).cuda()
+        with torch.no_grad():
+            for act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LRELU):
+                new, old = both(lambda: ops.conv2d_infer(x, wt, b, padding=1, act=act, slope=0.2))
+                assert torch.equal(new, old), ("act", act, n, h, w, cout)
+            new, old = both(lambda: ops.conv2d_infer(x, wt, None, padding=1, resid=res))
+            assert torch.equal(new, old), ("resid", n, h, w, cout)
+            # data gradients: dy has 64 channels, dx `cout` channels, masked by the (Leaky)ReLU output the forward conv consumed
+            wd = (torch.randn(64, cout, 3, 3, generator=g) * 0.05).cuda()                 # forward weight [Cout_fwd = 64, Cin_fwd = cout]
+            img = ops.pack_weight(wd, None, torch.bfloat16, ops._roundup(cout, 128), 64, 1)
+            mask = torch.randn(n, h, w, cout, generator=g).to(torch.bfloat16).cuda()
+            for ms in (0.0, 0.2):
+                new, old = both(lambda: ops.conv_dgrad(x, img, 3, 3, 1, 1, (h, w), cout, relu_mask=mask, mask_slope=ms))
+                assert torch.equal(new, old), ("mask", ms, n, h, w, cout)
+            new, old = both(lambda: ops.conv_dgrad(x, img, 3, 3, 1, 1, (h, w), cout))
+            assert torch.equal(new, old), ("dgrad", n, h, w, cout)
+    # the new kernel really ran: its launches are shorter than the shipped kernel's on the benchmarked shape (also a smoke timing)
+    x = torch.randn(8, 512, 512, 64, generator=g).to(torch.bfloat16).cuda()
+    wt = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).cuda()
+    b = torch.zeros(64).cuda()
+    times = []
+    with torch.no_grad():
+        for on in (1, 0):
+            be.mg_set_option(22, on)
+            for _ in range(3):
+                ops.conv2d_infer(x, wt, b, padding=1, act=ops.ACT_RELU)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(10):
+                ops.conv2d_infer(x, wt, b, padding=1, act=ops.ACT_RELU)
+            e.record(); torch.cuda.synchronize()
+            times.append(s.elapsed_time(e) / 10 * 1e3)
+        be.mg_set_option(22, 1)
+    print("64 -> 64 @ 8x512^2 (bias + ReLU): halo64 %.1f us, shipped halo kernel %.1f us; %.2f TB/s of algorithmic traffic" % (times[0], times[1], 2 * x.numel() * 2 / times[0] / 1e6))
+    assert times[0] < times[1]
+    # contract check of one case against the float64 emulator
+    from oracle.cabi_emulator import EmulatorBackend
+    from michigan_amd import _cabi
+    xs = torch.randn(2, 512, 512, 64, generator=g).to(torch.bfloat16)
+    ws = (torch.randn(64, 64, 3, 3, generator=g) * 0.05)
+    bs = torch.randn(64, generator=g)
+    with torch.no_grad():
+        got = ops.conv2d_infer(xs.cuda(), ws.cuda(), bs.cuda(), padding=1, act=ops.ACT_RELU).float().cpu()
+    prev = _cabi.set_backend(EmulatorBackend())
+    try:
+        with torch.no_grad():
+            want = ops.conv2d_infer(xs, ws, bs, padding=1, act=ops.ACT_RELU).float()
+    finally:
+        _cabi.set_backend(prev)
+    assert (got - want).abs().max().item() <= 2.0 ** -8 * want.abs().max().item()
+    # not taken: ragged tiles (520 = 32.5 tiles) and a launch with too few tiles -- still correct through the shipped kernels
+    with torch.no_grad():
+        for n, h, w in ((2, 520, 512), (1, 128, 128)):
+            x = torch.randn(n, h, w, 64, generator=g).to(torch.bfloat16).cuda()
+            new, old = both(lambda: ops.conv2d_infer(x, wt, b, padding=1))
+            assert torch.equal(new, old)

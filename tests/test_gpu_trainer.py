@@ -36,7 +36,8 @@ def test_trainer_fp32_matches_reference_trainer_golden(hip_backend, tag):
 
 def test_trainer_with_weight_gradients_on_the_side_stream_matches_reference_golden(hip_backend):
     """ops.sink_wgrad (the default; MG_WGRAD_STREAM=0 turns it off): the gradient sink's wgrad launches on a second HIP stream -- event-ordered behind the producer of
-    dy, joined before the arena is drained / reduced / re-zeroed, operands held by record_stream -- must give the reference trainer's
+    dy, joined before the arena is drained / reduced / re-zeroed, operands kept REFERENCED from Python until their launch's event has completed
+    (record_stream would not stop autograd from accumulating into dy in place) -- must give the reference trainer's
     numbers at the same tolerances as the in-stream order (fixture B: --use_ig, two G+D iterations, weights and statistics compared);
     and the side stream must really have been used."""
     from michigan_amd import ops

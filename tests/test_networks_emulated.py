@@ -190,3 +190,40 @@ def test_folded_leaky_relu_mask_equals_the_two_step_backward(emulator_backend, m
     for k, g in grads["fold"].items():
         h = grads["plain"][k]                                  # (biases in front of an instance norm have zero gradient: pure rounding noise)
         assert (g - h).abs().max().item() <= 1e-5 * max(h.abs().max().item(), 1e-2 * gmax), k
+
+
+def test_fold_expectations_survive_a_second_pass_in_the_same_graph_and_expire_with_their_graph(emulator_backend, monkeypatch):
+    """the mask-protocol check is keyed on expectations recorded at forward time.  A second grad-mode generator pass must not
+    clear the first pass's expectations while that pass's graph is alive (its backward is still to come and is still checked); once a graph
+    has been dropped without a backward, its expectations go at the next generator forward (no meeting a recycled address later)."""
+    import gc
+    import random
+    import michigan_amd.model as M
+    from michigan_amd import ops
+    from michigan_amd.synth import synth_batch
+    import parity_utils as PU
+    torch.manual_seed(5)
+    monkeypatch.setattr(ops, "MASK_PROTOCOL_CHECK", True)
+    monkeypatch.setattr(ops, "FUSE_LRELU_MASK", True)
+    model = M.Pix2PixModel(PU.small_opt(ngf=8, ndf=8, crop_size=64, random_expand_mask=False))
+    d = model.preprocess_input(synth_batch(2, 64, seed=7))
+    ops.reset_mask_protocol()
+    random.seed(2)
+    fake1 = model.generate_fake(d)
+    n1 = len(ops._FOLD_EXPECTED)
+    assert n1 >= 14                                             # norm_0 and norm_1 of the seven residual blocks
+    random.seed(2)
+    fake2 = model.generate_fake(d)                              # second pass, first graph still alive
+    assert len(ops._FOLD_EXPECTED) == 2 * n1
+    (fake1.float().square().mean() + fake2.float().square().mean()).backward()     # both backward passes run checked, and consume their expectations
+    assert len(ops._FOLD_EXPECTED) == 0
+    random.seed(2)
+    fake3 = model.generate_fake(d)                              # a pass whose graph is dropped without a backward ...
+    assert len(ops._FOLD_EXPECTED) == n1
+    del fake3
+    gc.collect()
+    random.seed(2)
+    fake4 = model.generate_fake(d)                              # ... is forgotten at the next forward
+    assert len(ops._FOLD_EXPECTED) == n1
+    fake4.float().square().mean().backward()
+    assert len(ops._FOLD_EXPECTED) == 0

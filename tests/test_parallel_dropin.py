@@ -441,6 +441,23 @@ def _job_side_effects_worker(rank, world, port, q, ckdir):
     assert torch.equal(sd["weight"], net.weight.detach()) and torch.equal(sd["bias"], net.bias.detach())
     assert [f for f in os.listdir(os.path.dirname(path)) if ".tmp." in f] == []
     assert next(net.parameters()).device.type == "cpu"
+    # a FAILED rank-0 write reaches every rank (parallel.rank0_write: what the drop-in's save_network and the native Pix2PixModel.save /
+    # Pix2PixTrainer.save share) and leaves neither a torn target nor the temporary file
+    from michigan_amd import parallel
+
+    def boom(tmp):
+        with open(tmp, "w") as fh:
+            fh.write("partial")
+        raise OSError("no space left on device")
+    failed = None
+    try:
+        parallel.rank0_write(os.path.join(ckdir, "job", "broken.pth"), boom, group=dist.group.WORLD)
+    except OSError:
+        failed = "oserror"
+    except RuntimeError as e:
+        failed = "runtime" if "rank 0 failed to write" in str(e) else None
+    assert failed == ("oserror" if rank == 0 else "runtime"), failed
+    assert sorted(os.listdir(os.path.join(ckdir, "job"))) == ["latest_net_G.pth"]
 
     # a dataset the reference's name lookup finds (data/__init__.py:16-38): 37 samples, each its own index
     from data.base_dataset import BaseDataset
