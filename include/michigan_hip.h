@@ -514,7 +514,8 @@ int mg_probe_tr16(const uint16_t* in /* [64][4] elements via LDS */, uint16_t* o
  * 9 = weight-slab ring depth of the big halo tile (3 default, or 4); 15 = 1: the SPADE halo kernel loads x in its epilogue instead of
  * ahead of its K loop (default 0); 17 = 1: two K slices also for 161..320-workgroup launches with >= 256 K steps (default 0);
  * 18 = stages a split of the generic weight-gradient kernel keeps at least (default 32); 22 = the register-resident-weights kernel for 3x3 convolutions
- * over exactly 64 input channels (mg_conv_halo64.hip; bitwise the results of the kernel it replaces).
+ * over exactly 64 input channels (mg_conv_halo64.hip; bitwise the results of the kernel it replaces); 24 = pixel width of the column stripes the
+ * kernel-row 3x3 weight-gradient kernel walks inside an image (a multiple of 32; default 64; 0 = whole image rows in raster order).
  * Results agree within accumulation-order rounding whatever the setting (each setting is bit-reproducible except
  * the weight gradients, which use fp32 atomics).
  * MEASUREMENT builds (wrong or no results, timing only; tools/probe_halo.py, tools/probe_wgrad3x3.py): key 10 = 1..6 variants of the big

@@ -25,6 +25,7 @@ extern int g_mg_norm_bwd_vec;      // mg_norm.hip (mg_set_option(19, v))
 extern int g_mg_wgrad_min_stages;  // mg_wgrad.hip (mg_set_option(18, v))
 extern int g_mg_conv_thin;         // mg_conv_thin.hip (mg_set_option(6, v))
 extern int g_mg_conv_dot;          // mg_conv_dot.hip (mg_set_option(8, v))
+extern int g_mg_wgrad3x3_stripe;   // mg_wgrad3x3.hip (mg_set_option(24, v))
 extern int g_mg_conv_halo64;       // mg_conv_halo64.hip (mg_set_option(22, v))
 extern int g_mg_conv_halo64_dbg;   // mg_conv_halo64.hip (mg_set_option(23, bits)): measurement only
 int g_mg_conv_noxpre = 0;        // mg_set_option(15, 1): A/B switch, the SPADE halo kernel loads x in its epilogue instead of ahead of the main loop
@@ -612,5 +613,6 @@ extern "C" int mg_set_option(int32_t key, int32_t value)
 #endif
     if (key == 22 && (value == 0 || value == 1)) { g_mg_conv_halo64 = value; return MG_OK; }
     if (key == 23 && value >= 0 && value <= 7) { g_mg_conv_halo64_dbg = value; return MG_OK; }
+    if (key == 24 && value >= 0 && value <= 4096 && (value % 32) == 0) { g_mg_wgrad3x3_stripe = value; return MG_OK; }
     return mg_fail(MG_ERR_ARG, "mg_set_option: unknown key/value %d/%d", key, value);
 }

@@ -376,7 +376,7 @@ int route_wgrad(const mg_wgrad_desc* d, hipStream_t st, float* dw, float* dbias,
         Wg3K k3;
         k3.x = d->x; k3.dy = d->dy; k3.dw = dw; k3.dbias = dbias;
         k3.N = d->N; k3.H = d->Hin; k3.W = d->Win; k3.Cin = d->Cin; k3.Cg = d->Cg;
-        k3.nstg = 0; k3.sps = 0; k3.tiles_m = k3.tiles_n = 0; k3.splitk = 0; k3.det_stride = det_stride; k3.half_cu = 0;
+        k3.nstg = 0; k3.sps = 0; k3.tiles_m = k3.tiles_n = 0; k3.splitk = 0; k3.det_stride = det_stride; k3.half_cu = 0; k3.stripe_w = 0;
         if (std3x3 && wgrad_thin_applies(k3)) return launch_wgrad_thin(k3, st, nsplit, dry);
     }
     if (wgrad_thin_taps_applies(d)) return launch_wgrad_thin_taps(d, st, dw, dbias, det_stride, nsplit, dry);
@@ -390,7 +390,7 @@ int route_wgrad(const mg_wgrad_desc* d, hipStream_t st, float* dw, float* dbias,
             k3.x = d->x; k3.dy = d->dy; k3.dw = dw; k3.dbias = dbias;
             k3.N = d->N; k3.H = d->Hin; k3.W = d->Win; k3.Cin = d->Cin; k3.Cg = d->Cg;
             k3.nstg = k.K / 32; k3.sps = 0; k3.tiles_m = k3.tiles_n = 0; k3.splitk = d->splitk; k3.det_stride = det_stride;
-            k3.half_cu = (d->flags & 2) ? 1 : 0;
+            k3.half_cu = (d->flags & 2) ? 1 : 0; k3.stripe_w = 0;
             return launch_wgrad3x3(k3, st, nsplit, dry);
         }
     }

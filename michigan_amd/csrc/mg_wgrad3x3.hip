@@ -17,6 +17,7 @@
 #include "mg_wgrad_common.h"
 
 extern int g_mg_wgrad3x3_probe;    // mg_conv.hip, mg_set_option(12, v): 1 = launch the stamped build of wgrad3x3_kernel<2, 2>
+int g_mg_wgrad3x3_stripe = 64;     // mg_set_option(24, v): pixel width of the column stripes the stages walk (0 = plain raster order over whole image rows)
 
 namespace {
 
@@ -104,12 +105,35 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wg3K d)
         boff[j] = (((r + ky - 1) * W + c) * d.Cin + ch) * 2;
         brc[j] = row < PR ? (r | (c + 1) << 4) : -1;
     }
-    const unsigned char* abase = reinterpret_cast<const unsigned char*>(d.dy) + (size_t)sbeg * 32 * d.Cg * 2;
-    const unsigned char* xbase = reinterpret_cast<const unsigned char*>(d.x) + (size_t)sbeg * 32 * d.Cin * 2;
-    const int a_step = 32 * d.Cg * 2, x_step = 32 * d.Cin * 2;
+    // Stage order.  W16: two 16-pixel rows per stage, raster order.  Otherwise an image is walked in COLUMN STRIPES of d.stripe_w pixels, each
+    // stripe top to bottom: the three kernel-row workgroups of a pixel range read X rows y - 1, y, y + 1 for output row y, i.e. every X row
+    // three times, one image row apart -- with whole-width rows (16 stages at W = 512, ~17 MB of other traffic through the XCD's 4 MiB L2 in
+    // between) every re-read went back to the fabric (TCC hit rate 52 %, 1.5x the algorithmic bytes, profiles/r05_pmc_halo.txt); with 64-pixel
+    // stripes the re-read comes two stages later and hits (round 6).  stripe_w = W is the old order.
+    const unsigned char* const dy0 = reinterpret_cast<const unsigned char*>(d.dy);
+    const unsigned char* const x0p = reinterpret_cast<const unsigned char*>(d.x);
+    const unsigned char* abase; const unsigned char* xbase;
     int sy, sx, sg_next = sbeg;                               // image row / column of the next stage to issue
-    { const int rem = (sbeg * 32) % (H * W); sy = rem / W; sx = rem - sy * W; }
+    int simg = 0, sstripe = 0;                                // (stripe order) image and stripe of the next stage
+    const int SWp = W16 ? W : d.stripe_w, nsegs = SWp / 32, nstripes = W / SWp;
+    if (W16) {
+        abase = dy0 + (size_t)sbeg * 32 * d.Cg * 2;
+        xbase = x0p + (size_t)sbeg * 32 * d.Cin * 2;
+        const int rem = (sbeg * 32) % (H * W); sy = rem / W; sx = rem - sy * W;
+    } else {
+        const int spi = H * (W / 32);                         // stages per image
+        simg = sbeg / spi;
+        int r = sbeg - simg * spi;
+        sstripe = r / (H * nsegs);  r -= sstripe * (H * nsegs);
+        sy = r / nsegs;
+        sx = sstripe * SWp + (r - sy * nsegs) * 32;
+        const size_t p = ((size_t)simg * H + sy) * W + sx;
+        abase = dy0 + p * d.Cg * 2;
+        xbase = x0p + p * d.Cin * 2;
+    }
     sy = __builtin_amdgcn_readfirstlane(sy); sx = __builtin_amdgcn_readfirstlane(sx);     // wave-uniform: the bounds tests of issue() stay scalar
+    simg = __builtin_amdgcn_readfirstlane(simg); sstripe = __builtin_amdgcn_readfirstlane(sstripe);
+    const int a_step = 32 * d.Cg * 2, x_step = 32 * d.Cin * 2;
 
     // The DMA issue sits beside the other workgroup's MFMA stream, where a wave gets roughly one VALU issue per 10 cycles: with the
     // bounds tests, selects and 64-bit adds done per lane it was 0.36 us of a 1.23 us stage (tools/probe_wgrad3x3.py).  Validity of a lane
@@ -161,9 +185,21 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const Wg3K d)
             glds16(reinterpret_cast<const void*>((size_t)(((unsigned long long)phi << 32) | plo)),
                    __builtin_amdgcn_readfirstlane(live ? sbase + A_BYTES + j * 4096 + wave * 1024 : dump));
         }
-        abase += a_step; xbase += x_step; ++sg_next;
-        if (W16) { sy += 2; } else { sx += 32; if (sx >= W) { sx = 0; ++sy; } }
-        if (sy >= H) sy = 0;
+        ++sg_next;
+        if (W16) {
+            abase += a_step; xbase += x_step;
+            sy += 2; if (sy >= H) sy = 0;
+        } else {
+            sx += 32;
+            if (sx < (sstripe + 1) * SWp) { abase += a_step; xbase += x_step; }
+            else {                                            // end of the stripe's row: next row of the stripe, next stripe, next image
+                sx = sstripe * SWp; ++sy;
+                if (sy >= H) { sy = 0; ++sstripe; if (sstripe >= nstripes) { sstripe = 0; ++simg; } sx = sstripe * SWp; }
+                const size_t p = ((size_t)simg * H + sy) * W + sx;
+                abase = dy0 + p * d.Cg * 2;
+                xbase = x0p + p * d.Cin * 2;
+            }
+        }
     };
 
     f32x16_t acc[3][MT][NT];
@@ -295,6 +331,7 @@ int launch3(Wg3K& k, hipStream_t st, int* nsplit, bool dry)
     constexpr size_t LDS = 4 * (size_t)STAGE + 4096;
     k.tiles_m = (k.Cg + TM - 1) / TM;
     k.tiles_n = (k.Cin + TN - 1) / TN;
+    k.stripe_w = (!W16 && g_mg_wgrad3x3_stripe >= 32 && (g_mg_wgrad3x3_stripe % 32) == 0 && k.W > g_mg_wgrad3x3_stripe && (k.W % g_mg_wgrad3x3_stripe) == 0) ? g_mg_wgrad3x3_stripe : k.W;
     const long base = 3L * k.tiles_m * k.tiles_n;
     // Split-K: every split adds one pass of fp32 atomics over the whole dW (~1.5 TB/s), while the main loop is
     // already near its rate with ~1.5 workgroups per CU (tools/wgrad_split_sweep.py): use ~384 workgroups, more

@@ -12,6 +12,7 @@ struct Wg3K {
     int splitk;             // requested split count (0 = choose)
     long det_stride;        // deterministic mode: floats per split slab (dw / dbias then point INTO the workspace), 0 = fp32 atomics
     int half_cu;            // mg_wgrad_desc.flags bit 1: leave half of every CU to the other stream (one workgroup of this kernel per CU)
+    int stripe_w;           // stage order inside an image: column stripes of this many pixels (a multiple of 32), each walked top to bottom; W = plain raster order
 };
 
 // One partial value of split `split`: an fp32 atomic into the shared dW, or (deterministic mode) a plain store into the split's own slab.
