@@ -355,7 +355,7 @@ def main():
             live = None
             if a.mode == "train" and world == 1 and not a.no_traffic:
                 live = measure_traffic_in_run(a)
-            tfile = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r05_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json")) if os.path.exists(f)), "")
+            tfile = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r06_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json")) if os.path.exists(f)), "")
             # ^ tools/pmc_step.sh (rocprofv3 --pmc passes, separate runs): the fallback when rocprofv3 is not available in this run
             if live is not None:
                 roof["traffic"] = live.get("dominant_gb_per_launch") if dn else None

@@ -78,7 +78,7 @@ class SPADEBGenerator(BaseNetwork):
         # The conditioning pyramid and the hair-mask pyramid depend on the inputs only.  A training step runs the generator twice on
         # the same batch (generator step, then under no_grad for the discriminator step): the second pass re-uses them (~50 small
         # launches) when it is handed the very same tensor objects, unmodified (identity through weak references + version counters).
-        src = (input_tag, orient_mask)
+        src = (input_tag, orient_mask) + ((noise,) if getattr(opt, "orient_random_disturb", False) and not opt.no_orientation else ())
         # inference tensors have no version counter (torch.inference_mode): they bypass the cache
         cacheable = INPUT_CACHE and not any(t is not None and t.is_inference() for t in src)
         key = hit = None
@@ -96,7 +96,10 @@ class SPADEBGenerator(BaseNetwork):
                 else:
                     orient = orient_mask
                 if opt.orient_random_disturb:
-                    raise NotImplementedError("--orient_random_disturb is outside the BASELINE configs")
+                    # generator.py:136-140: inside a 5-pixel band along the hair mask's border (get_wide_edges, :98-105: mask minus its
+                    # erosion) the orientation is replaced by noise channel 0.  Two-channel 512^2 maps: glue, not a kernel.
+                    edges = hair - (1 - F.max_pool2d(1 - hair, kernel_size=5, stride=1, padding=2))
+                    orient = orient.float() * (1 - edges) + edges * noise[:, :1].float()
                 seg = torch.cat([seg, orient.float()], dim=1)
             hh, hw = hair.shape[2], hair.shape[3]
             nup = {"normal": 5, "more": 6, "most": 7}[opt.num_upsampling_layers]

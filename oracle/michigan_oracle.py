@@ -186,6 +186,11 @@ def spadeb_generator(sd: SD, opt, input_ref, orient_mask, image_ref, input_tag, 
             orient_in = torch.cat([torch.sin(2 * o1), torch.cos(2 * o1)], dim=1) * seg[:, 1:2]
         else:
             orient_in = orient_mask
+        if getattr(opt, "orient_random_disturb", False):
+            # generator.py:136-140 + get_wide_edges :98-105: a 5-pixel band inside the hair mask's border takes noise channel 0 instead of the orientation
+            t = input_tag[:, 1:2]
+            edges = t - (1 - F.max_pool2d(1 - t, kernel_size=5, stride=1, padding=2))
+            orient_in = orient_in * (1 - edges) + edges * noise[:, :1]
         seg = torch.cat([seg, orient_in], dim=1)
     if dilate_k == "auto":
         dilate_k = background_dilate_k(input_tag.shape[2], opt)

@@ -124,3 +124,39 @@ def test_oracle_orientation_loss_matches_reference():
     want_o, want_c = crit(fake, b["orient"], b["input_tag"])
     got_o, got_c = O.orientation_loss(fake, b["orient"], b["input_tag"], use_ig=True)
     assert abs(float(want_o) - float(got_o)) < 1e-6 and abs(float(want_c) - float(got_c)) < 1e-5
+
+
+@needs_ref
+def test_orient_random_disturb_matches_reference_and_hip_classes_match_the_oracle():
+    """--orient_random_disturb (reference generator.py:98-105,136-140; VERDICT r5 "missing" 5): the oracle against the LIVE reference generator,
+    then this repo's generator (contract emulator) against the oracle -- same weights, same inputs, both use_ig forms of the orientation map."""
+    from michigan_amd import _cabi, networks
+    from michigan_amd.model import default_options
+    from michigan_amd.synth import synth_batch, synth_loader_batch, synth_state_dict
+    from oracle.cabi_emulator import EmulatorBackend
+    for use_ig in (True, False):
+        opt = R.make_opt(ngf=8, ndf=8, crop_size=64, random_expand_mask=False, orient_random_disturb=True, use_ig=use_ig)
+        G = R.build_generator(opt).train()
+        sd = synth_state_dict(G.state_dict(), seed=24, gain=1.1)
+        G.load_state_dict(sd)
+        b = synth_batch(2, 64, seed=9)
+        orient = b["orient"] if use_ig else synth_loader_batch(2, 64, seed=9)["orient"]
+        random.seed(5)
+        ref = G(b["input_ref"], orient_mask=orient, image_ref=b["image_ref"], input_tag=b["input_tag"], noise=b["noise"], image_tag=b["image_tag"])
+        random.seed(5)
+        out = O.spadeb_generator(sd, opt, b["input_ref"], orient, b["image_ref"], b["input_tag"], b["noise"], b["image_tag"], True, {})
+        assert (out - ref).abs().max().item() < 1e-4
+        plain = O.spadeb_generator(sd, R.make_opt(ngf=8, ndf=8, crop_size=64, random_expand_mask=False, use_ig=use_ig), b["input_ref"], orient,
+                                   b["image_ref"], b["input_tag"], b["noise"], b["image_tag"], True, {})
+        assert (out - plain).abs().max().item() > 1e-3                      # the option really changes the conditioning
+        prev = _cabi.set_backend(EmulatorBackend())
+        try:
+            hopt = default_options(ngf=8, ndf=8, crop_size=64, gpu_ids=[], compute_dtype="fp32", random_expand_mask=False, orient_random_disturb=True, use_ig=use_ig)
+            H = networks.SPADEBGenerator(hopt).train()
+            H.load_state_dict(sd)
+            random.seed(5)
+            with torch.no_grad():
+                got = H(b["input_ref"], orient_mask=orient, image_ref=b["image_ref"], input_tag=b["input_tag"], noise=b["noise"], image_tag=b["image_tag"])
+        finally:
+            _cabi.set_backend(prev)
+        assert (got.float() - ref).abs().max().item() < 2e-4
