@@ -36,5 +36,6 @@ for N in 2 4 8; do
     line grads_in_stream   $N MG_DP_GRAD_SIDE=0
     line single_stream     $N MG_WGRAD_STREAM=0
     line no_branch_streams $N MG_BRANCH_STREAMS=0
+    line native_comm       $N MG_COMM=native
 done
 echo "# scaling efficiency = value(N) / (N x value(1)); the >= 6.5x target of BASELINE.json is value(8) / value(1) at this per-GPU batch"
