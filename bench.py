@@ -410,6 +410,10 @@ def main():
         if per_rank_ms is not None:
             out["per_rank_ms_per_step"] = per_rank_ms           # each rank's own clock up to its last kernel; `ms_per_step` is the max incl. the barrier
             out["rank_spread_ms"] = round(max(per_rank_ms) - min(per_rank_ms), 3)
+        if world > 1 or os.environ.get("MG_DP_FORCE") == "1":
+            from michigan_amd import parallel as _p
+            out["config"]["collectives"] = ("C ABI: mg_allreduce_stats / mg_allreduce_grads over RCCL (MG_COMM=native)" if _p.native_comm() is not None
+                                            else "torch.distributed all_reduce (backend %s)" % backend)
         if roof is not None and world > 1:
             out["collectives_per_step"] = collectives          # RCCL all-reduces one rank issues per G+D step, by kind
         if roof is not None and syncbn_ms is not None:

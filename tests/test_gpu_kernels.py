@@ -1391,6 +1391,22 @@ def test_halo64_matches_the_shipped_halo_kernel_bitwise(hip_backend):
     finally:
         _cabi.set_backend(prev)
     assert (got - want).abs().max().item() <= 2.0 ** -8 * want.abs().max().item()
+    # race screen: the kernel hands patches and auxiliary quads through LDS-DMA behind one barrier per tile -- 150 launches of a residual case on a
+    # busy GPU (a second stream streams HBM beside it) must all give the first launch's bytes
+    xr = torch.randn(4, 512, 512, 64, generator=g).to(torch.bfloat16).cuda()
+    rr = torch.randn(4, 512, 512, 64, generator=g).to(torch.bfloat16).cuda()
+    junk = torch.empty(1 << 27, dtype=torch.float32, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.no_grad():
+        first = ops.conv2d_infer(xr, wt, b, padding=1, resid=rr).clone()
+        bad = 0
+        for it in range(150):
+            if it % 10 == 0:
+                with torch.cuda.stream(side):
+                    junk.add_(1.0)
+            bad += int(not torch.equal(ops.conv2d_infer(xr, wt, b, padding=1, resid=rr), first))
+    torch.cuda.synchronize()
+    assert bad == 0, "%d of 150 launches differ from the first" % bad
     # not taken: ragged tiles (520 = 32.5 tiles) and a launch with too few tiles -- still correct through the shipped kernels
     with torch.no_grad():
         for n, h, w in ((2, 520, 512), (1, 128, 128)):

@@ -14,7 +14,7 @@ SRC, DST = os.path.join(ROOT, "gpurun_out", TAG), os.path.join(ROOT, "profiles")
 NAMES = {
     "bench.json": "r06_bench_bs8_bf16.json", "kernel_stats.csv": "r06_bench_bs8_bf16_kernel_stats.csv",
     "kernel_stats_single_stream.csv": "r06_bench_bs8_bf16_kernel_stats_single_stream.csv",
-    "bench_bs4.json": "r06_bench_bs4_bf16.json", "bench_rccl1.json": "r06_bench_rccl1_one_rank_forced.json", "bench_single_stream.json": "r06_bench_bs8_bf16_single_stream.json",
+    "bench_bs4.json": "r06_bench_bs4_bf16.json", "bench_bs1.json": "r06_bench_bs1_bf16.json", "bench_native1.json": "r06_bench_native_comm_one_rank_forced.json", "bench_rccl1.json": "r06_bench_rccl1_one_rank_forced.json", "bench_single_stream.json": "r06_bench_bs8_bf16_single_stream.json",
     "conv_census.txt": "r06_conv_census.txt", "pytest_gpu.log": "r06_pytest_gpu_tail.txt", "rc.log": "r06_evidence_rc.txt",
 }
 NOISE = ("amdgpu.ids", "Network [")
