@@ -405,6 +405,7 @@ def main():
                                       "vs_minimum_work": round(value * step_gflop_min / 1e3 / world, 1),
                                       "gflop_per_image": [step_gflop_ref, step_gflop_min], "unit": "TFLOP/s per GPU"},
             "losses": losses,
+            "second_stream_probe": [{"device": d_, "candidates_tried": n_, "overlaps_compute_stream": ok_} for d_, n_, ok_ in __import__("michigan_amd.ops", fromlist=["_STREAM_PROBE_LOG"])._STREAM_PROBE_LOG],
             "peak_memory_gb": peak_mem,                         # torch.cuda.max_memory_allocated: the timed region (streams as configured) / the extra single-stream step
         }
         if per_rank_ms is not None:

@@ -502,12 +502,61 @@ _WGRAD_STREAMS = {}            # device index -> [stream, dirty, held]: held = [
 WGRAD_HELD_BUDGET = int(os.environ.get("MG_WGRAD_HELD_MB", "6144")) << 20
 
 
+def streams_overlap(main, cand) -> bool:
+    """Do kernels on `cand` really run beside kernels on `main`?  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by
+    default) in creation order; two streams that land on one queue serialise, whatever the API says.  Probe: a ~0.4 ms element-wise pass on `main`,
+    a tiny kernel on `cand` issued right behind it with no dependency; `cand` overlaps when its kernel finishes before main's does."""
+    dev = main.device
+    big = torch.empty(64 << 20, dtype=torch.float32, device=dev)            # 256 MiB: ~0.1 ms per pass at 5 TB/s
+    small = torch.zeros(64, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
+    votes = 0
+    for _ in range(3):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        with torch.cuda.stream(main):
+            e0.record(main)
+            for _ in range(4):
+                big.add_(1.0)
+            e1.record(main)
+        with torch.cuda.stream(cand):
+            small.add_(1.0)
+            e2.record(cand)
+        torch.cuda.synchronize(dev)
+        votes += int(e0.elapsed_time(e2) < 0.6 * e0.elapsed_time(e1))
+    return votes >= 2
+
+
+STREAM_PROBE = os.environ.get("MG_STREAM_PROBE", "1") != "0"      # pick a second stream that is on another hardware queue than the compute stream
+_STREAM_PROBE_LOG = []                                             # (device index, attempts, overlaps) of every side stream created: bench.py reports it
+
+
 def _new_side_stream(device):
     """The side stream is an ordinary stream at torch's default priority.  One created at the device's LOWEST priority
     (hipStreamCreateWithPriority) measured the same single-GPU gain (65.1 -> 63.6 vs 64.6 -> 63.3 ms) but cost 16 ms per step as soon as the
     step contained RCCL collectives (one rank, every collective forced: 83.5 ms against 65.6 with this stream and 67.1 with no side stream
-    at all, whichever stream the collectives were issued on: profiles/r05_side_stream_ab.txt) -- removed."""
-    return torch.cuda.Stream(device=device)
+    at all, whichever stream the collectives were issued on: profiles/r05_side_stream_ab.txt) -- removed.
+    Round 6: WHICH hardware queue a stream lands on is decided by creation order, and an RCCL communicator created in between shifts it: with
+    the C ABI's communicator in the process the step ran 70.7 ms instead of 63.5 without a single collective being issued, 63.2 again under
+    GPU_MAX_HW_QUEUES=8 -- and torch's own communicator showed the mirror image (83.9 ms under GPU_MAX_HW_QUEUES=8; profiles/r06_hw_queues.txt).
+    So the stream is PROBED: candidates are created until one measurably overlaps the compute stream (the rejected ones stay alive -- they hold
+    their queue slot); the outcome is kept for bench.py's line."""
+    main = torch.cuda.current_stream(device)
+    if not STREAM_PROBE:
+        return torch.cuda.Stream(device=device)
+    rejected = []
+    for attempt in range(1, 9):
+        cand = torch.cuda.Stream(device=device)
+        if streams_overlap(main, cand):
+            _STREAM_PROBE_LOG.append((device.index, attempt, True))
+            _REJECTED_STREAMS.extend(rejected)
+            return cand
+        rejected.append(cand)
+    _STREAM_PROBE_LOG.append((device.index, 8, False))
+    _REJECTED_STREAMS.extend(rejected[1:])
+    return rejected[0]
+
+
+_REJECTED_STREAMS = []
 
 
 def _wgrad_side(device):

@@ -107,7 +107,7 @@ class NativeComm:
             self.be.mg_allreduce_grads(self.handle, chunk.data_ptr(), chunk.numel(), ctypes.c_void_p(cur.cuda_stream))
             return None
         if self.stream is None:
-            self.stream = torch.cuda.Stream(device=chunk.device)
+            self.stream = ops._new_side_stream(chunk.device)   # probed: on another hardware queue than the compute stream (ops.streams_overlap)
         self.stream.wait_stream(cur)
         self.be.mg_allreduce_grads(self.handle, chunk.data_ptr(), chunk.numel(), ctypes.c_void_p(self.stream.cuda_stream))
         ev = torch.cuda.Event()
