@@ -9,7 +9,7 @@ from michigan_amd.synth import synth_batch
 torch.manual_seed(0)
 opt = default_options(crop_size=512, gpu_ids=[0], compute_dtype="bf16")
 tr = Pix2PixTrainer(opt)
-data = {k: v.cuda() for k, v in synth_batch(8, 512, seed=1234).items()}
+data = {k: v.cuda() for k, v in synth_batch(int(sys.argv[1]) if len(sys.argv) > 1 else 8, 512, seed=1234).items()}
 def step():
     tr.run_generator_one_step(data); tr.run_discriminator_one_step(data)
 for _ in range(3): step()
