@@ -96,8 +96,15 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t: torch.Tensor):
+    """The hipStream_t the launch goes to: torch's CURRENT stream of the tensor's device.  torch._C._cuda_getCurrentRawStream returns the handle
+    without building a torch.cuda.Stream object (~0.4 us instead of ~5 us; ~1100 launches per step, and the step is host-bound at one image per GPU)."""
     if t.is_cuda:
+        if _RAW_STREAM is not None:
+            return ctypes.c_void_p(_RAW_STREAM(t.device.index))
         return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
     return None
 
