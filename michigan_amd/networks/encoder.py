@@ -128,10 +128,13 @@ class BackgroundEncode2(BaseNetwork):
     def __init__(self, opt):
         super().__init__()
         self.opt, self.ngf = opt, opt.ngf
-        if opt.num_upsampling_layers == "most":
-            raise NotImplementedError("num_upsampling_layers='most' is outside the BASELINE configs")
         ngf = opt.ngf
-        self.conv1 = ConvBlock(3, ngf, 7, 1, 3)
+        self.most = opt.num_upsampling_layers == "most"
+        if self.most:                                      # encoder.py:276-278: a half-width 7x7 at full resolution, then one more stride-2 level
+            self.conv0 = ConvBlock(3, ngf // 2, 7, 1, 3)
+            self.layer0 = ConvBlock(ngf // 2, ngf, 4, 2, 1)
+        else:
+            self.conv1 = ConvBlock(3, ngf, 7, 1, 3)
         self.layer1 = ConvBlock(ngf, 2 * ngf, 4, 2, 1)
         self.layer2 = ConvBlock(2 * ngf, 4 * ngf, 4, 2, 1)
         self.layer3 = ConvBlock(4 * ngf, 8 * ngf, 4, 2, 1)
@@ -179,14 +182,19 @@ class BackgroundEncode2(BaseNetwork):
             inp = noise if self.opt.random_noise_background else image * back + noise * (1 - back)
             x_in = ops.pad_channels(ops.to_nhwc(inp, dt), 8)
         # every feature map feeds the next layer AND the generator's blend (ConvBlock ends in a ReLU): two-consumer taps
-        x0, f0 = ops.act_tap(self.conv1(x_in))
+        if self.most:
+            x00, f00 = ops.act_tap(self.conv0(x_in))
+            x0, f0 = ops.act_tap(self.layer0(x00))
+        else:
+            x0, f0 = ops.act_tap(self.conv1(x_in))
         x1, f1 = ops.act_tap(self.layer1(x0))
         x2, f2 = ops.act_tap(self.layer2(x1))
         x3 = f3 = self.layer3(x2)
         sh, sw = back.shape[2], back.shape[3]
+        levels = (16, 8, 4, 2) if self.most else (8, 4, 2)
         if back.dtype == torch.float32 and back.is_contiguous():
-            masks = ops.nearest_pyramid([back.detach()[:, 0]], [(int(sh / d), int(sw / d)) for d in (8, 4, 2)], 1, torch.float32)
+            masks = ops.nearest_pyramid([back.detach()[:, 0]], [(int(sh / d), int(sw / d)) for d in levels], 1, torch.float32)
             masks = [m.reshape(m.shape[0], 1, m.shape[1], m.shape[2]) for m in masks] + [back]
         else:
-            masks = [F.interpolate(back, size=(int(sh / d), int(sw / d)), mode="nearest") for d in (8, 4, 2)] + [back]
-        return [f3, f2, f1, f0], masks
+            masks = [F.interpolate(back, size=(int(sh / d), int(sw / d)), mode="nearest") for d in levels] + [back]
+        return ([f3, f2, f1, f0, f00] if self.most else [f3, f2, f1, f0]), masks

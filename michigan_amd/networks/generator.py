@@ -47,9 +47,11 @@ class SPADEBGenerator(BaseNetwork):
         self.up_1 = SPADEResnetBlock(8 * nf, 4 * nf, opt)
         self.up_2 = SPADEResnetBlock(4 * nf, 2 * nf, opt)
         self.up_3 = SPADEResnetBlock(2 * nf, 1 * nf, opt)
-        if opt.num_upsampling_layers == "most":
-            raise NotImplementedError("num_upsampling_layers='most' is outside the BASELINE configs")
-        self.conv_img = HipConv2d(nf, 3, 3, padding=1)
+        final_nc = nf
+        if opt.num_upsampling_layers == "most":            # generator.py:66-68: one more block at the output resolution, half width
+            self.up_4 = SPADEResnetBlock(1 * nf, nf // 2, opt)
+            final_nc = nf // 2
+        self.conv_img = HipConv2d(final_nc, 3, 3, padding=1)
         self.backgroud_enc = BackgroundEncode2(opt)
 
     def compute_latent_vector_size(self, opt):
@@ -104,12 +106,13 @@ class SPADEBGenerator(BaseNetwork):
             hh, hw = hair.shape[2], hair.shape[3]
             nup = {"normal": 5, "more": 6, "most": 7}[opt.num_upsampling_layers]
             pyramid = SegPyramid(seg, dt, sizes=[(self.sh << i, self.sw << i) for i in range(nup + 1)])     # the SPADE layers' resolutions
+            levels = (16, 8, 4, 2) if nup == 7 else (8, 4, 2)        # generator.py:150-159
             if hair.dtype == torch.float32:
                 hp = hair.detach()[:, 0]
-                hair_masks = ops.nearest_pyramid([hp], [(int(hh / d), int(hw / d)) for d in (8, 4, 2)], 1, torch.float32)
+                hair_masks = ops.nearest_pyramid([hp], [(int(hh / d), int(hw / d)) for d in levels], 1, torch.float32)
                 hair_masks = [m.reshape(m.shape[0], 1, m.shape[1], m.shape[2]) for m in hair_masks] + [hair]
             else:
-                hair_masks = [F.interpolate(hair, size=(int(hh / d), int(hw / d)), mode="nearest") for d in (8, 4, 2)] + [hair]
+                hair_masks = [F.interpolate(hair, size=(int(hh / d), int(hw / d)), mode="nearest") for d in levels] + [hair]
             if cacheable:
                 self.__dict__["_mg_input_cache"] = (key, tuple(weakref.ref(t) for t in src if t is not None), pyramid, hair_masks)
 
@@ -117,10 +120,11 @@ class SPADEBGenerator(BaseNetwork):
 
         x = self.head_0(x, pyramid)
         x = self.G_middle_0(x, pyramid, up=True)
-        x = self.G_middle_1(x, pyramid, up=opt.num_upsampling_layers == "more")
-        for i, block in enumerate((self.up_0, self.up_1, self.up_2, self.up_3)):
+        x = self.G_middle_1(x, pyramid, up=opt.num_upsampling_layers in ("more", "most"))
+        blocks = (self.up_0, self.up_1, self.up_2, self.up_3) + ((self.up_4,) if opt.num_upsampling_layers == "most" else ())
+        for i, block in enumerate(blocks):
             x = block(x, pyramid, up=True)            # the 2x nearest upsample is folded into the block's first SPADE layers
-            last = i == 3
+            last = i == len(blocks) - 1
             if opt.bf_direct_add:
                 x = back_feats[i] + x
                 x = F.leaky_relu(x, 0.2) if last else x

@@ -155,17 +155,25 @@ def background_dilate_k(mask_h: int, opt) -> Optional[int]:
 
 
 def background_encode2(image, mask, noise, sd: SD, prefix: str, opt, k: Optional[int]):
-    """BackgroundEncode2.forward (num_upsampling_layers != 'most', add_feat_zeros False), encoder.py:286-341."""
+    """BackgroundEncode2.forward (add_feat_zeros False), encoder.py:286-341; 'most' adds conv0 / layer0 and a fifth level (:276-278,323-327,338-339)."""
     if k is None:
         back = mask[:, 0:1]
     else:
         back = 1 - F.max_pool2d(mask[:, 1:2], kernel_size=k, stride=1, padding=int(k / 2))
     inp = noise if opt.random_noise_background else image * back + noise * (1 - back)
-    x0 = conv_block_relu(inp, sd[prefix + "conv1.conv.weight"], sd[prefix + "conv1.conv.bias"], 1, 3)
+    most = getattr(opt, "num_upsampling_layers", "more") == "most"
+    if most:
+        x00 = conv_block_relu(inp, sd[prefix + "conv0.conv.weight"], sd[prefix + "conv0.conv.bias"], 1, 3)
+        x0 = conv_block_relu(x00, sd[prefix + "layer0.conv.weight"], sd[prefix + "layer0.conv.bias"], 2, 1)
+    else:
+        x0 = conv_block_relu(inp, sd[prefix + "conv1.conv.weight"], sd[prefix + "conv1.conv.bias"], 1, 3)
     x1 = conv_block_relu(x0, sd[prefix + "layer1.conv.weight"], sd[prefix + "layer1.conv.bias"], 2, 1)
     x2 = conv_block_relu(x1, sd[prefix + "layer2.conv.weight"], sd[prefix + "layer2.conv.bias"], 2, 1)
     x3 = conv_block_relu(x2, sd[prefix + "layer3.conv.weight"], sd[prefix + "layer3.conv.bias"], 2, 1)
     sh, sw = back.shape[2], back.shape[3]
+    if most:
+        masks = [F.interpolate(back, size=(int(sh / d), int(sw / d)), mode="nearest") for d in (16, 8, 4, 2)] + [back]
+        return [x3, x2, x1, x0, x00], masks
     masks = [F.interpolate(back, size=(int(sh / d), int(sw / d)), mode="nearest") for d in (8, 4, 2)] + [back]
     return [x3, x2, x1, x0], masks
 
@@ -175,7 +183,7 @@ def spadeb_generator(sd: SD, opt, input_ref, orient_mask, image_ref, input_tag, 
                      taps: Optional[Dict[str, torch.Tensor]] = None):
     """SPADEBGenerator.forward with use_encoder / partialconv / noise_background /
     num_upsampling_layers='more' (generator.py:107-230)."""
-    num_up = {"normal": 5, "more": 6}[opt.num_upsampling_layers]
+    num_up = {"normal": 5, "more": 6, "most": 7}[opt.num_upsampling_layers]
     sw = (opt.crop_size + (opt.add_th if opt.add_feat_zeros else 0)) // (2 ** num_up)
     sh = round(sw / opt.aspect_ratio)
     x = image_encoder3(image_ref, input_ref[:, 1:2], input_tag[:, 1:2], sd, "fc.", sw, sh)
@@ -197,7 +205,8 @@ def spadeb_generator(sd: SD, opt, input_ref, orient_mask, image_ref, input_tag, 
     back_feats, back_masks = background_encode2(image_tag, input_tag, noise, sd, "backgroud_enc.", opt, dilate_k)
     hair = input_tag[:, 1:2]
     hh, hw = hair.shape[2], hair.shape[3]
-    hair_masks = [F.interpolate(hair, size=(int(hh / d), int(hw / d)), mode="nearest") for d in (8, 4, 2)] + [hair]
+    levels = (16, 8, 4, 2) if num_up == 7 else (8, 4, 2)                 # generator.py:150-159
+    hair_masks = [F.interpolate(hair, size=(int(hh / d), int(hw / d)), mode="nearest") for d in levels] + [hair]
 
     def up(t):
         return F.interpolate(t, scale_factor=2, mode="nearest")
@@ -212,7 +221,7 @@ def spadeb_generator(sd: SD, opt, input_ref, orient_mask, image_ref, input_tag, 
     if num_up >= 6:
         x = up(x)
     x = tap("G_middle_1", spade_resblock(x, seg, sd, "G_middle_1.", training, updates))
-    for i in range(4):
+    for i in range(5 if num_up == 7 else 4):                             # 'most': up_4 (ngf -> ngf / 2) behind a seventh upsample, generator.py:66-68,221-224
         x = tap(f"up_{i}_block", spade_resblock(up(x), seg, sd, f"up_{i}.", training, updates))
         x = tap(f"up_{i}", back_feats[i] * (1 - hair_masks[i]) + x * (1 - back_masks[i]))
     x = F.conv2d(F.leaky_relu(x, 0.2), sd["conv_img.weight"], sd["conv_img.bias"], padding=1)

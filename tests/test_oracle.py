@@ -160,3 +160,45 @@ def test_orient_random_disturb_matches_reference_and_hip_classes_match_the_oracl
         finally:
             _cabi.set_backend(prev)
         assert (got.float() - ref).abs().max().item() < 2e-4
+
+
+@needs_ref
+def test_most_upsampling_matches_reference_and_hip_classes_match_the_oracle():
+    """--num_upsampling_layers most (reference generator.py:66-68,84,156-159,221-224, encoder.py:276-278,323-327,338-339: a seventh upsample, `up_4` at half
+    width, `conv0` / `layer0` in the background encoder, five blend levels): the oracle against the LIVE reference generator, forward and the
+    gradients of a few parameters the variant adds, then this repo's generator (contract emulator) against the oracle."""
+    from michigan_amd import _cabi, networks
+    from michigan_amd.model import default_options
+    from michigan_amd.synth import synth_batch, synth_state_dict
+    from oracle.cabi_emulator import EmulatorBackend
+    opt = R.make_opt(ngf=16, ndf=8, crop_size=256, random_expand_mask=False, num_upsampling_layers="most")
+    G = R.build_generator(opt).train()
+    sd = synth_state_dict(G.state_dict(), seed=25, gain=1.1)
+    assert "up_4.conv_0.weight_orig" in sd and "backgroud_enc.conv0.conv.weight" in sd and sd["conv_img.weight"].shape[1] == 8
+    G.load_state_dict(sd)
+    b = synth_batch(2, 256, seed=10)
+    names = ["up_4.conv_0.weight_orig", "up_4.norm_s.mlp_gamma.weight", "backgroud_enc.conv0.conv.weight", "backgroud_enc.layer0.conv.weight", "conv_img.weight"]
+    random.seed(5)
+    ref = G(b["input_ref"], orient_mask=b["orient"], image_ref=b["image_ref"], input_tag=b["input_tag"], noise=b["noise"], image_tag=b["image_tag"])
+    assert ref.shape == (2, 3, 256, 256)
+    gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3))
+    (ref * gy).sum().backward()
+    want = {n: p.grad.clone() for n, p in G.named_parameters() if n in names}
+    random.seed(5)
+    out = O.spadeb_generator(sd, opt, b["input_ref"], b["orient"], b["image_ref"], b["input_tag"], b["noise"], b["image_tag"], True, {})
+    assert (out - ref.detach()).abs().max().item() < 1e-4
+    prev = _cabi.set_backend(EmulatorBackend())
+    try:
+        hopt = default_options(ngf=16, ndf=8, crop_size=256, gpu_ids=[], compute_dtype="fp32", random_expand_mask=False, num_upsampling_layers="most")
+        H = networks.SPADEBGenerator(hopt).train()
+        assert list(H.state_dict().keys()) == list(G.state_dict().keys())       # same keys, same order as the reference's 'most' generator
+        H.load_state_dict(sd)
+        random.seed(5)
+        got = H(b["input_ref"], orient_mask=b["orient"], image_ref=b["image_ref"], input_tag=b["input_tag"], noise=b["noise"], image_tag=b["image_tag"])
+        (got.float() * gy).sum().backward()
+        grads = {n: p.grad.clone() for n, p in H.named_parameters() if n in names}
+    finally:
+        _cabi.set_backend(prev)
+    assert (got.detach().float() - ref.detach()).abs().max().item() < 2e-4
+    for n in names:
+        assert (grads[n] - want[n]).norm().item() <= 2e-3 * want[n].norm().item(), n
