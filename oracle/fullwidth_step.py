@@ -28,7 +28,7 @@ import torch
 CFG_FULL = dict(tag="F", ngf=64, ndf=64, crop=512, n=1, iters=1, use_ig=False, seed_g=51, seed_d=52, seed_v=53, seed_x=55,
                 seed_ig=57, seed_py=300, gain=1.0, vgg_gain=1.4)
 # the plumbing of this protocol is exercised on the CPU (reference vs the float64 contract emulator) at a width the emulator finishes in seconds
-CFG_SMALL = dict(CFG_FULL, tag="S", ngf=8, ndf=8, crop=128)
+CFG_SMALL = dict(CFG_FULL, tag="S", ngf=8, ndf=8, crop=128)          # (crop 64 makes the latent 1x1: two-value batch statistics are too ill-conditioned to compare gradients at 2e-3)
 
 # generator parameters whose gradients are recorded: one of every kind of wide layer (spectral-normed 3x3 at 1024 / 512 / 128 channels, a 1x1
 # shortcut, gamma / beta convs and biases, the label-map conv, both encoders, the image conv)
