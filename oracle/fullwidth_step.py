@@ -27,6 +27,7 @@ import torch
 
 CFG_FULL = dict(tag="F", ngf=64, ndf=64, crop=512, n=1, iters=1, use_ig=False, seed_g=51, seed_d=52, seed_v=53, seed_x=55,
                 seed_ig=57, seed_py=300, gain=1.0, vgg_gain=1.4)
+CFG_FULL_BS2 = dict(CFG_FULL, tag="F2", n=2, seed_x=65)       # two samples: batch statistics across samples, the discriminator's fake | real stacking at 2 + 2
 # the plumbing of this protocol is exercised on the CPU (reference vs the float64 contract emulator) at a width the emulator finishes in seconds
 CFG_SMALL = dict(CFG_FULL, tag="S", ngf=8, ndf=8, crop=128)          # (crop 64 makes the latent 1x1: two-value batch statistics are too ill-conditioned to compare gradients at 2e-3)
 
@@ -193,9 +194,9 @@ def distances(rec, ref):
 if __name__ == "__main__":
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cfg", default="full", choices=["full", "small"])
+    ap.add_argument("--cfg", default="full", choices=["full", "full_bs2", "small"])
     ap.add_argument("--out", required=True)
     ap.add_argument("--threads", type=int, default=None)
     a = ap.parse_args()
-    rec = reference_record(CFG_FULL if a.cfg == "full" else CFG_SMALL, a.out, a.threads)
+    rec = reference_record({"full": CFG_FULL, "full_bs2": CFG_FULL_BS2, "small": CFG_SMALL}[a.cfg], a.out, a.threads)
     print("reference record: %d keys -> %s" % (len(rec), a.out))
