@@ -241,6 +241,9 @@ def main():
     backend = os.environ.get("MG_BENCH_BACKEND", "nccl")       # "gloo" lets two ranks share one GPU in a smoke test
     local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
+    # measurement aid (tools/queue_shift_ab.sh): K streams created up front shift which hardware queue every later stream -- torch's process-group
+    # stream, RCCL's own, the second compute stream -- lands on (HIP hands out GPU_MAX_HW_QUEUES queues in creation order)
+    _dummy_streams = [torch.cuda.Stream() for _ in range(int(os.environ.get("MG_BENCH_DUMMY_STREAMS", "0")))]
     if world > 1 or os.environ.get("MG_DP_FORCE") == "1":     # MG_DP_FORCE: one-rank RCCL exercise of the DP path (michigan_amd/parallel.py)
         if backend == "nccl":
             # communicators are created lazily, one ncclCommInitRank per group at its first collective (the long-standing path); MG_NCCL_EAGER=1
