@@ -272,6 +272,12 @@ class Pix2PixModel(nn.Module):
                     losses["GAN"] = self.criterionGAN(pred_fake, True, for_discriminator=False, label=label)
                 if self.opt.curr_step == 1 and ref_is_tag and not self.opt.no_ganFeat_loss:
                     losses["GAN_Feat"] = self.criterionGANFeat(pred_fake, pred_real, label)
+                if int(ops.BRANCH_STREAMS) >= 3 and not getattr(self.opt, "no_orient_loss", True):
+                    # (A/B, MG_BRANCH_STREAMS=3) the Gabor orientation branch behind the discriminator branch on the side stream, beside the VGG tower
+                    orient, conf = self.criterionOrient(fake, d["orient"], d["input_tag"])
+                    losses["ORIENT"] = _scaled(orient, self.opt.lambda_orient)
+                    if not self.opt.no_confidence_loss:
+                        losses["CONFIDENCE"] = conf * self.opt.lambda_confidence
         else:
             pred_fake, pred_real = self.discriminate(d, fake, split=True)
             if not self.opt.no_gan_loss:
@@ -286,14 +292,14 @@ class Pix2PixModel(nn.Module):
                     for t in y_feats:
                         t.record_stream(main)
                 losses["VGG"] = _scaled(self.criterionVGG(fake, d["image_tag"], label, y_feats=y_feats), self.opt.lambda_vgg)
-        if not getattr(self.opt, "no_orient_loss", True):
+        if not getattr(self.opt, "no_orient_loss", True) and "ORIENT" not in losses:
             orient, conf = self.criterionOrient(fake, d["orient"], d["input_tag"])
             losses["ORIENT"] = _scaled(orient, self.opt.lambda_orient)
             if not self.opt.no_confidence_loss:
                 losses["CONFIDENCE"] = conf * self.opt.lambda_confidence
         if branch:
             main.wait_stream(side)                                # the D branch's loss scalars are summed on the main stream
-            for k in ("GAN", "GAN_Feat"):
+            for k in ("GAN", "GAN_Feat") + (("ORIENT", "CONFIDENCE") if int(ops.BRANCH_STREAMS) >= 3 else ()):
                 if k in losses and torch.is_tensor(losses[k]):
                     losses[k].record_stream(main)
         return losses, fake
